@@ -1,0 +1,186 @@
+"""Thin Python view of the C ABI (include/icpx.h): one Context per GPU.
+
+Arrays may be numpy arrays (host memory) or torch CUDA tensors (device memory, used in place on the
+context's GPU). torch is only plumbing here: device memory and streams.
+"""
+import ctypes as C
+import numpy as np
+
+from .lib import icpx, IcpxError, BnbItem
+
+HOST, DEVICE = 0, 1
+NSUMS = 16
+MAXROTLEVEL = 20
+
+
+def _is_torch(a):
+    return hasattr(a, "data_ptr") and hasattr(a, "is_cuda")
+
+
+def _ptr(a, dtype, shape_last=None):
+    """(pointer, where, count) of a C-contiguous numpy array or CUDA tensor of the given dtype."""
+    if _is_torch(a):
+        import torch
+        want = {np.float32: torch.float32, np.float64: torch.float64, np.int32: torch.int32}[dtype]
+        if a.dtype != want or not a.is_contiguous() or not a.is_cuda:
+            raise TypeError(f"expected a contiguous CUDA tensor of {want}")
+        return C.c_void_p(a.data_ptr()), DEVICE
+    if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags.c_contiguous:
+        raise TypeError(f"expected a C-contiguous numpy array of {np.dtype(dtype)}")
+    return a.ctypes.data_as(C.c_void_p), HOST
+
+
+class Context:
+    def __init__(self, device=0):
+        self._lib = icpx()
+        h = C.c_void_p()
+        rc = self._lib.icpx_create(device, C.byref(h))
+        if rc != 0:
+            raise IcpxError(rc, self._lib.icpx_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.icpx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise IcpxError(rc, self._lib.icpx_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, stream_ptr):
+        self._ck(self._lib.icpx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def sync(self):
+        self._ck(self._lib.icpx_sync(self._h))
+
+    # ---- target / NN ----
+    def set_target(self, xyz):
+        p, where = _ptr(xyz, np.float32)
+        n, stride = xyz.shape[0], 4 * xyz.shape[1]
+        self._ck(self._lib.icpx_set_target(self._h, p, n, stride, where))
+
+    def nn(self, q, want_d2=True):
+        p, where = _ptr(q, np.float64)
+        n = q.shape[0]
+        if where == DEVICE:
+            import torch
+            idx = torch.empty(n, dtype=torch.int32, device=q.device)
+            d2 = torch.empty(n, dtype=torch.float64, device=q.device) if want_d2 else None
+            pi, pd = C.c_void_p(idx.data_ptr()), (C.c_void_p(d2.data_ptr()) if want_d2 else None)
+        else:
+            idx = np.empty(n, np.int32)
+            d2 = np.empty(n, np.float64) if want_d2 else None
+            pi, pd = idx.ctypes.data_as(C.c_void_p), (d2.ctypes.data_as(C.c_void_p) if want_d2 else None)
+        self._ck(self._lib.icpx_nn(self._h, p, n, where, pi, pd))
+        return idx, d2
+
+    def nn_distance(self, q):
+        p, where = _ptr(q, np.float32)
+        n = q.shape[0]
+        if where == DEVICE:
+            import torch
+            out = torch.empty(n, dtype=torch.float32, device=q.device); po = C.c_void_p(out.data_ptr())
+        else:
+            out = np.empty(n, np.float32); po = out.ctypes.data_as(C.c_void_p)
+        self._ck(self._lib.icpx_nn_distance(self._h, p, n, where, po))
+        return out
+
+    # ---- ICP step ----
+    def set_source(self, xyz):
+        p, where = _ptr(xyz, np.float32)
+        self._ck(self._lib.icpx_set_source(self._h, p, xyz.shape[0], 4 * xyz.shape[1], where))
+        self._ns = xyz.shape[0]
+
+    def icp_step(self, T, want_idx=False):
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        sums = np.empty(NSUMS, np.float64)
+        idx = np.empty(self._ns, np.int32) if want_idx else None
+        self._ck(self._lib.icpx_icp_step(self._h, T.ctypes.data_as(C.c_void_p), sums.ctypes.data_as(C.c_void_p),
+                                         idx.ctypes.data_as(C.c_void_p) if want_idx else None, HOST))
+        return (sums, idx) if want_idx else sums
+
+    def icp_step_async(self, T, sums_dev):
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        p, where = _ptr(sums_dev, np.float64)
+        assert where == DEVICE
+        self._ck(self._lib.icpx_icp_step_async(self._h, T.ctypes.data_as(C.c_void_p), p))
+
+    # ---- EDT ----
+    def edt_build(self, div, box=None):
+        if box is None:
+            self._ck(self._lib.icpx_edt_build(self._h, div))
+        else:
+            mn = np.ascontiguousarray(box[0], np.float32)
+            self._ck(self._lib.icpx_edt_build_box(self._h, div, mn.ctypes.data_as(C.c_void_p), C.c_float(box[1])))
+
+    def edt_rebuild_async(self):
+        self._ck(self._lib.icpx_edt_rebuild_async(self._h))
+
+    def edt_info(self):
+        div = C.c_uint32(); mn = (C.c_float * 3)(); cell = C.c_float(); occ = C.c_uint64(); dr = C.c_uint64()
+        self._ck(self._lib.icpx_edt_info(self._h, C.byref(div), mn, C.byref(cell), C.byref(occ), C.byref(dr)))
+        return dict(div=div.value, min=np.array(list(mn), np.float32), cell=np.float32(cell.value), occupied=occ.value,
+                    dropped=dr.value)
+
+    def edt_read(self, out=None):
+        div = self.edt_info()["div"]
+        if out is None:
+            out = np.empty((div, div, div), np.int32)
+        p, where = _ptr(out, np.int32)
+        self._ck(self._lib.icpx_edt_read(self._h, p, where))
+        return out
+
+    def edt_lookup(self, q):
+        p, where = _ptr(q, np.float32)
+        n = q.shape[0]
+        if where == DEVICE:
+            import torch
+            out = torch.empty(n, dtype=torch.float32, device=q.device); po = C.c_void_p(out.data_ptr())
+        else:
+            out = np.empty(n, np.float32); po = out.ctypes.data_as(C.c_void_p)
+        self._ck(self._lib.icpx_edt_lookup(self._h, p, n, where, po))
+        return out
+
+    # ---- Go-ICP ----
+    def goicp_set_data(self, xyz):
+        p, where = _ptr(xyz, np.float32)
+        self._ck(self._lib.icpx_goicp_set_data(self._h, p, xyz.shape[0], 4 * xyz.shape[1], where))
+        self._nd = xyz.shape[0]
+
+    def goicp_maxrotdist(self):
+        out = np.empty((MAXROTLEVEL, self._nd), np.float32)
+        self._ck(self._lib.icpx_goicp_read_maxrotdist(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    @staticmethod
+    def make_items(Rs, cubes, levels):
+        """Rs: n x 9 float, cubes: n x 4 (x,y,z,w), levels: n ints (-1 = upper-bound form)."""
+        n = len(cubes)
+        arr = (BnbItem * n)()
+        for i in range(n):
+            for k in range(9):
+                arr[i].R[k] = float(Rs[i][k])
+            arr[i].x, arr[i].y, arr[i].z, arr[i].w = (float(v) for v in cubes[i])
+            arr[i].level = int(levels[i])
+        return arr
+
+    def bnb_eval(self, items, want_mindis=False):
+        n = len(items)
+        ub = np.empty(n, np.float64); lb = np.empty(n, np.float64)
+        md = np.empty((n, self._nd), np.float32) if want_mindis else None
+        self._ck(self._lib.icpx_bnb_eval(self._h, C.cast(items, C.c_void_p), n, ub.ctypes.data_as(C.c_void_p),
+                                         lb.ctypes.data_as(C.c_void_p), md.ctypes.data_as(C.c_void_p) if want_mindis else None))
+        return (ub, lb, md) if want_mindis else (ub, lb)
+
+    def goicp_residuals(self, T):
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        out = np.empty(self._nd, np.float32)
+        self._ck(self._lib.icpx_goicp_residuals(self._h, T.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out

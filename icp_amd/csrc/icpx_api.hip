@@ -1,0 +1,268 @@
+// Context management, staging and the small shared kernels of the icpx C ABI.
+#include <cstring>
+#include <cfloat>
+#include <new>
+
+#include "icpx_ctx.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+static thread_local std::string g_create_error = "";
+
+int icpx_bind(icpx_ctx* ctx) {
+    ICPX_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    return ICPX_OK;
+}
+
+int icpx_reserve(icpx_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return ICPX_OK;
+    if (b.p) {
+        ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ICPX_CHECK_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        ctx->set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        return ICPX_ENOMEM;
+    }
+    b.cap = want;
+    return ICPX_OK;
+}
+
+int icpx_launch_check(icpx_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ctx->set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return ICPX_EHIP;
+    }
+    return ICPX_OK;
+}
+
+extern "C" int icpx_create(int device, icpx_ctx** out) {
+    if (!out) { g_create_error = "icpx_create: out is NULL"; return ICPX_EINVAL; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("icpx_create: no HIP device available (") + hipGetErrorString(e) + ")";
+        return ICPX_EHIP;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "icpx_create: device index out of range";
+        return ICPX_EINVAL;
+    }
+    icpx_ctx* ctx = new (std::nothrow) icpx_ctx;
+    if (!ctx) { g_create_error = "icpx_create: out of host memory"; return ICPX_ENOMEM; }
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("icpx_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return ICPX_EHIP;
+    }
+    ctx->stream = ctx->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    *out = ctx;
+    return ICPX_OK;
+}
+
+extern "C" void icpx_destroy(icpx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->tgt_xyz, &ctx->cell_range, &ctx->sorted_pts, &ctx->sort_keys_a, &ctx->sort_keys_b,
+                      &ctx->sort_vals_a, &ctx->sort_vals_b, &ctx->sort_tmp, &ctx->src_pts, &ctx->partials, &ctx->sums,
+                      &ctx->scratch_q, &ctx->scratch_idx, &ctx->scratch_d2, &ctx->scratch_f, &ctx->edt_bits,
+                      &ctx->edt_rowlist, &ctx->edt_rowcnt, &ctx->edt_planelist, &ctx->edt_counters, &ctx->edt_plane,
+                      &ctx->edt_sq, &ctx->data_pts, &ctx->maxrot, &ctx->bnb_items, &ctx->bnb_partials, &ctx->bnb_out,
+                      &ctx->bnb_mindis};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char* icpx_last_error(const icpx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int icpx_set_stream(icpx_ctx* ctx, void* hip_stream) {
+    if (!ctx) return ICPX_EINVAL;
+    ICPX_TRY(icpx_bind(ctx));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ICPX_OK;
+}
+
+extern "C" int icpx_sync(icpx_ctx* ctx) {
+    if (!ctx) return ICPX_EINVAL;
+    ICPX_TRY(icpx_bind(ctx));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+extern "C" int icpx_device(const icpx_ctx* ctx) { return ctx ? ctx->device : -1; }
+
+// ---- staging ---------------------------------------------------------------------------------------
+
+__global__ void k_pack_points4(const char* __restrict__ src, size_t n, size_t stride, float4* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = reinterpret_cast<const float*>(src + i * stride);
+    dst[i] = make_float4(p[0], p[1], p[2], __int_as_float((int)i));
+}
+
+int icpx_stage_points4(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, int where, float4* dst) {
+    const char* dsrc = reinterpret_cast<const char*>(xyz);
+    if (where == ICPX_HOST) {
+        const size_t bytes = (n - 1) * stride_bytes + 12;
+        ICPX_TRY(icpx_reserve(ctx, ctx->scratch_f, bytes));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_f.p, xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+        dsrc = ctx->scratch_f.as<char>();
+    }
+    const int threads = 256;
+    const unsigned blocks = (unsigned)((n + threads - 1) / threads);
+    hipLaunchKernelGGL(k_pack_points4, dim3(blocks), dim3(threads), 0, ctx->stream, dsrc, n, stride_bytes, dst);
+    return icpx_launch_check(ctx, "k_pack_points4");
+}
+
+// Per-block min / max of float4 points -> partial[block] = {min xyz, max xyz}.
+__global__ __launch_bounds__(256) void k_bbox_partial(const float4* __restrict__ pts, size_t n, float* __restrict__ partial) {
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float4 p = pts[i];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+    __shared__ float sm[6][4];
+    for (int c = 0; c < 3; c++) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) for (int c = 0; c < 3; c++) { sm[c][wave] = mn[c]; sm[3 + c][wave] = mx[c]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sm[threadIdx.x][0];
+        for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? fminf(v, sm[threadIdx.x][w]) : fmaxf(v, sm[threadIdx.x][w]);
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+static int device_bbox4(icpx_ctx* ctx, const float4* pts, size_t n, float mn[3], float mx[3]) {
+    const int blocks = (int)std::min<size_t>(1024, (n + 255) / 256);
+    ICPX_TRY(icpx_reserve(ctx, ctx->partials, sizeof(float) * 6 * 1024));
+    hipLaunchKernelGGL(k_bbox_partial, dim3(blocks), dim3(256), 0, ctx->stream, pts, n, ctx->partials.as<float>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_bbox_partial"));
+    std::vector<float> h(6 * blocks);
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(h.data(), ctx->partials.p, sizeof(float) * 6 * blocks, hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < 3; c++) { mn[c] = h[c]; mx[c] = h[3 + c]; }
+    for (int b = 1; b < blocks; b++)
+        for (int c = 0; c < 3; c++) { mn[c] = std::min(mn[c], h[6 * b + c]); mx[c] = std::max(mx[c], h[6 * b + 3 + c]); }
+    return ICPX_OK;
+}
+
+__device__ __forceinline__ unsigned spread10(unsigned v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ void k_morton_keys(const float4* __restrict__ pts, size_t n, float3 mn, float3 scale, unsigned* __restrict__ keys,
+                              unsigned* __restrict__ vals) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pts[i];
+    unsigned ix = (unsigned)fminf(fmaxf((p.x - mn.x) * scale.x, 0.f), 1023.f);
+    unsigned iy = (unsigned)fminf(fmaxf((p.y - mn.y) * scale.y, 0.f), 1023.f);
+    unsigned iz = (unsigned)fminf(fmaxf((p.z - mn.z) * scale.z, 0.f), 1023.f);
+    keys[i] = spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2);
+    vals[i] = (unsigned)i;
+}
+
+__global__ void k_gather4(const float4* __restrict__ src, const unsigned* __restrict__ order, size_t n, float4* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[order[i]];
+}
+
+// Sorts (keys_a, vals_a) -> (keys_b, vals_b), stable, on the context stream.
+int icpx_sort_pairs(icpx_ctx* ctx, size_t n, unsigned end_bit) {
+    size_t tmp = 0;
+    unsigned* ka = ctx->sort_keys_a.as<unsigned>(); unsigned* kb = ctx->sort_keys_b.as<unsigned>();
+    unsigned* va = ctx->sort_vals_a.as<unsigned>(); unsigned* vb = ctx->sort_vals_b.as<unsigned>();
+    ICPX_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, ka, kb, va, vb, n, 0, end_bit, ctx->stream));
+    ICPX_TRY(icpx_reserve(ctx, ctx->sort_tmp, tmp));
+    ICPX_CHECK_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, ka, kb, va, vb, n, 0, end_bit, ctx->stream));
+    return ICPX_OK;
+}
+
+int icpx_sort_reserve(icpx_ctx* ctx, size_t n) {
+    ICPX_TRY(icpx_reserve(ctx, ctx->sort_keys_a, n * 4));
+    ICPX_TRY(icpx_reserve(ctx, ctx->sort_keys_b, n * 4));
+    ICPX_TRY(icpx_reserve(ctx, ctx->sort_vals_a, n * 4));
+    ICPX_TRY(icpx_reserve(ctx, ctx->sort_vals_b, n * 4));
+    return ICPX_OK;
+}
+
+int icpx_morton_sort4(icpx_ctx* ctx, float4* pts, size_t n) {
+    float mn[3], mx[3];
+    ICPX_TRY(device_bbox4(ctx, pts, n, mn, mx));
+    float3 lo = make_float3(mn[0], mn[1], mn[2]);
+    float3 sc;
+    sc.x = mx[0] > mn[0] ? 1023.f / (mx[0] - mn[0]) : 0.f;
+    sc.y = mx[1] > mn[1] ? 1023.f / (mx[1] - mn[1]) : 0.f;
+    sc.z = mx[2] > mn[2] ? 1023.f / (mx[2] - mn[2]) : 0.f;
+    ICPX_TRY(icpx_sort_reserve(ctx, n));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_morton_keys, dim3(blocks), dim3(256), 0, ctx->stream, pts, n, lo, sc, ctx->sort_keys_a.as<unsigned>(),
+                       ctx->sort_vals_a.as<unsigned>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_morton_keys"));
+    ICPX_TRY(icpx_sort_pairs(ctx, n, 30));
+    // gather through a temporary copy
+    ICPX_TRY(icpx_reserve(ctx, ctx->scratch_q, n * sizeof(float4)));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, pts, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gather4, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scratch_q.as<float4>(), ctx->sort_vals_b.as<unsigned>(), n, pts);
+    return icpx_launch_check(ctx, "k_gather4");
+}
+
+// ---- target ------------------------------------------------------------------------------------------
+
+__global__ void k_unpack3(const float4* __restrict__ src, size_t n, float* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = src[i];
+    dst[3 * i] = p.x; dst[3 * i + 1] = p.y; dst[3 * i + 2] = p.z;
+}
+
+extern "C" int icpx_set_target(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, int where) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!xyz || n == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_set_target: empty target cloud");
+    if (stride_bytes < 12 || stride_bytes % 4) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_set_target: stride must be a multiple of 4 and >= 12");
+    if (n > 0x7fffffffu) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_set_target: more than 2^31-1 points");
+    ICPX_TRY(icpx_bind(ctx));
+    ctx->grid_ready = false;
+    ctx->edt_ready = false;
+    ICPX_TRY(icpx_reserve(ctx, ctx->sorted_pts, n * sizeof(float4)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->tgt_xyz, n * 3 * sizeof(float)));
+    float4* p4 = ctx->sorted_pts.as<float4>();
+    ICPX_TRY(icpx_stage_points4(ctx, xyz, n, stride_bytes, where, p4));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_unpack3, dim3(blocks), dim3(256), 0, ctx->stream, p4, n, ctx->tgt_xyz.as<float>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_unpack3"));
+    ICPX_TRY(device_bbox4(ctx, p4, n, ctx->bbmin, ctx->bbmax));
+    for (int c = 0; c < 3; c++)
+        if (!(ctx->bbmin[c] == ctx->bbmin[c]) || !(ctx->bbmax[c] - ctx->bbmin[c] < FLT_MAX))
+            ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_set_target: non-finite coordinates in the target cloud");
+    ctx->nt = n;
+    ICPX_TRY(icpx_grid_build(ctx));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}

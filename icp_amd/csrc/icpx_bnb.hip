@@ -1,0 +1,234 @@
+// Go-ICP bound evaluation: batched upper / lower bounds of translation cubes under given rotations.
+//
+// Stands in for the point loops of GoIcp::innerBnB (src/GoIcp.cpp:384-431), the rotation of the data
+// cloud in OuterBnB (:264-272), GoIcp::Init's uncertainty table (:459-480) and the SSE loop of runICP
+// (:113-135). One launch evaluates a whole batch of (rotation, translation cube, level) items; each
+// item is split over several workgroups so that small batches still fill the chip, and a second kernel
+// adds the per-workgroup partial sums in a fixed order.
+//
+// Arithmetic follows the reference per point in float: x' = (R11 x + R12 y) + R13 z, centre = corner +
+// w/2, d = Distance(x' + centre) - maxRotDist, clamped at 0 (built with -ffp-contract=off). The sums
+// are accumulated in double on the device; the per-point d can be written out for callers that need
+// the reference's sequential float sums.
+#include "icpx_ctx.h"
+#include "icpx_edt_dev.h"
+
+#include <cmath>
+
+
+namespace {
+
+#define GOICP_PI 3.1415926536     // src/GoIcp.cpp:17
+#define GOICP_SQRT3 1.732050808   // src/GoIcp.cpp:18
+
+struct EdtView {
+    const int* __restrict__ sq;
+    int div;
+    float mnx, mny, mnz, cell;
+};
+
+// norm in float (the SQ() macro multiplies floats and std::sqrt picks the float overload,
+// src/GoIcp.cpp:464-466), then (float)(c_level * (double)norm) with c_level = 2 sin(tmp/2) from the host.
+struct RotConsts { double c[ICPX_MAXROTLEVEL]; };
+
+__global__ void k_maxrotdist(const float4* __restrict__ data, size_t n, RotConsts rc, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = data[i];
+    const float nrm = __builtin_sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(p.x, p.x), __fmul_rn(p.y, p.y)), __fmul_rn(p.z, p.z)));
+#pragma unroll
+    for (int l = 0; l < ICPX_MAXROTLEVEL; l++) out[(size_t)l * n + i] = (float)__dmul_rn(rc.c[l], (double)nrm);
+}
+
+__global__ __launch_bounds__(256) void k_bnb_eval(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
+                                                  const icpx_bnb_item* __restrict__ items, int nsplit, double* __restrict__ partials,
+                                                  float* __restrict__ mindis) {
+    const int item = blockIdx.x, split = blockIdx.y;
+    const icpx_bnb_item it = items[item];
+    const float half = it.w / 2;
+    const float tx = it.x + half, ty = it.y + half, tz = it.z + half;
+    const float maxTransDis = (float)(GOICP_SQRT3 / 2.0 * (double)it.w);
+    const float* mr = it.level >= 0 ? maxrot + (size_t)it.level * n : nullptr;
+    const size_t per = (n + nsplit - 1) / nsplit;
+    const size_t lo = (size_t)split * per, hi = lo + per < n ? lo + per : n;
+    double ub = 0.0, lb = 0.0;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const float4 p = data[i];
+        const float rx = it.R[0] * p.x + it.R[1] * p.y + it.R[2] * p.z;
+        const float ry = it.R[3] * p.x + it.R[4] * p.y + it.R[5] * p.z;
+        const float rz = it.R[6] * p.x + it.R[7] * p.y + it.R[8] * p.z;
+        float d = edt_distance(e.sq, e.div, e.mnx, e.mny, e.mnz, e.cell, rx + tx, ry + ty, rz + tz);
+        if (mr) d -= mr[i];
+        if (d < 0) d = 0;
+        if (mindis) mindis[(size_t)item * n + __float_as_int(p.w)] = d;
+        ub += (double)(d * d);
+        const float dis = d - maxTransDis;
+        if (dis > 0) lb += (double)(dis * dis);
+    }
+    for (int o = 32; o > 0; o >>= 1) { ub += __shfl_xor(ub, o); lb += __shfl_xor(lb, o); }
+    __shared__ double sm[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][wave] = ub; sm[1][wave] = lb; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const double v = (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+        partials[((size_t)item * nsplit + split) * 2 + threadIdx.x] = v;
+    }
+}
+
+__global__ void k_bnb_reduce(const double* __restrict__ partials, int nitems, int nsplit, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nitems) return;
+    double ub = 0.0, lb = 0.0;
+    for (int s = 0; s < nsplit; s++) { ub += partials[((size_t)i * nsplit + s) * 2]; lb += partials[((size_t)i * nsplit + s) * 2 + 1]; }
+    out[i] = ub;
+    out[nitems + i] = lb;
+}
+
+struct Mat34 { double m[12]; };
+
+__global__ void k_goicp_residuals(EdtView e, const float4* __restrict__ data, size_t n, Mat34 T, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 s = data[i];
+    double p[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        double a = 0.0;
+        a += T.m[4 * r + 0] * (double)s.x;
+        a += T.m[4 * r + 1] * (double)s.y;
+        a += T.m[4 * r + 2] * (double)s.z;
+        a += T.m[4 * r + 3];
+        p[r] = a;
+    }
+    out[__float_as_int(s.w)] = edt_distance(e.sq, e.div, e.mnx, e.mny, e.mnz, e.cell, (float)p[0], (float)p[1], (float)p[2]);
+}
+
+EdtView edt_view(const icpx_ctx* ctx) {
+    EdtView e;
+    e.sq = ctx->edt_sq.as<int>(); e.div = (int)ctx->div;
+    e.mnx = ctx->edt_min[0]; e.mny = ctx->edt_min[1]; e.mnz = ctx->edt_min[2]; e.cell = ctx->edt_cell;
+    return e;
+}
+
+}  // namespace
+
+extern "C" int icpx_goicp_set_data(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, int where) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!xyz || n == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_goicp_set_data: empty data cloud");
+    if (stride_bytes < 12 || stride_bytes % 4) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_goicp_set_data: stride must be a multiple of 4 and >= 12");
+    if (n > 0x7fffffffu) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_goicp_set_data: more than 2^31-1 points");
+    ICPX_TRY(icpx_bind(ctx));
+    ctx->nd = 0;
+    ICPX_TRY(icpx_reserve(ctx, ctx->data_pts, n * sizeof(float4)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->maxrot, (size_t)ICPX_MAXROTLEVEL * n * sizeof(float)));
+    ICPX_TRY(icpx_stage_points4(ctx, xyz, n, stride_bytes, where, ctx->data_pts.as<float4>()));
+    ICPX_TRY(icpx_morton_sort4(ctx, ctx->data_pts.as<float4>(), n));
+    RotConsts rc;
+    const double initRotW = 2 * GOICP_PI;   // InitRot.w, src/GoIcp.cpp:88
+    for (int l = 0; l < ICPX_MAXROTLEVEL; l++) {
+        const double sigma = initRotW / std::pow(2.0, l) / 2.0;
+        double tmp = sigma * GOICP_SQRT3;
+        if (tmp > GOICP_PI) tmp = GOICP_PI;
+        rc.c[l] = 2 * std::sin(tmp / 2);
+    }
+    hipLaunchKernelGGL(k_maxrotdist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->data_pts.as<float4>(), n, rc,
+                       ctx->maxrot.as<float>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_maxrotdist"));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->nd = n;
+    return ICPX_OK;
+}
+
+__global__ void k_unsort_rows(const float* __restrict__ src, const float4* __restrict__ data, size_t n, int rows, float* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int o = __float_as_int(data[i].w);
+    for (int r = 0; r < rows; r++) dst[(size_t)r * n + o] = src[(size_t)r * n + i];
+}
+
+extern "C" int icpx_goicp_read_maxrotdist(icpx_ctx* ctx, float* out) {
+    if (!ctx) return ICPX_EINVAL;
+    if (ctx->nd == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_goicp_read_maxrotdist: no data cloud (call icpx_goicp_set_data first)");
+    if (!out) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_goicp_read_maxrotdist: out is NULL");
+    ICPX_TRY(icpx_bind(ctx));
+    const size_t n = ctx->nd, bytes = (size_t)ICPX_MAXROTLEVEL * n * sizeof(float);
+    ICPX_TRY(icpx_reserve(ctx, ctx->bnb_mindis, bytes));
+    hipLaunchKernelGGL(k_unsort_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->maxrot.as<float>(),
+                       ctx->data_pts.as<float4>(), n, ICPX_MAXROTLEVEL, ctx->bnb_mindis.as<float>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_unsort_rows"));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(out, ctx->bnb_mindis.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+static int bnb_enqueue(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev, float* mindis_dev) {
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_eval: no EDT has been built");
+    if (ctx->nd == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_eval: no data cloud (call icpx_goicp_set_data first)");
+    if (!items) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval: items is NULL");
+    if (nitems > 65535u * 16u) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_bnb_eval: more than 1048560 items in one batch");
+    for (size_t i = 0; i < nitems; i++)
+        if (items[i].level >= ICPX_MAXROTLEVEL) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval: item %zu has level %d >= %d", i, items[i].level, ICPX_MAXROTLEVEL);
+    const size_t n = ctx->nd;
+    int nsplit = (int)((4 * (size_t)ctx->num_cus + nitems - 1) / nitems);
+    const int maxsplit = (int)((n + 1023) / 1024);
+    if (nsplit > maxsplit) nsplit = maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    ICPX_TRY(icpx_reserve(ctx, ctx->bnb_items, nitems * sizeof(icpx_bnb_item)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->bnb_partials, nitems * nsplit * 2 * sizeof(double)));
+    // The item list is copied from pageable host memory: hipMemcpyAsync returns only after the source
+    // has been staged, so the caller may reuse `items` as soon as this function returns.
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->bnb_items.p, items, nitems * sizeof(icpx_bnb_item), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nitems, (unsigned)nsplit), dim3(256), 0, ctx->stream, edt_view(ctx),
+                       ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), ctx->bnb_items.as<icpx_bnb_item>(), nsplit,
+                       ctx->bnb_partials.as<double>(), mindis_dev);
+    hipLaunchKernelGGL(k_bnb_reduce, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bnb_partials.as<double>(),
+                       (int)nitems, nsplit, out_dev);
+    return icpx_launch_check(ctx, "k_bnb_eval");
+}
+
+extern "C" int icpx_bnb_eval(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* ub, double* lb, float* mindis_opt) {
+    if (!ctx) return ICPX_EINVAL;
+    if (nitems == 0) return ICPX_OK;
+    if (!ub || !lb) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval: ub / lb is NULL");
+    ICPX_TRY(icpx_bind(ctx));
+    ICPX_TRY(icpx_reserve(ctx, ctx->bnb_out, 2 * nitems * sizeof(double)));
+    float* md = nullptr;
+    if (mindis_opt) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->bnb_mindis, nitems * ctx->nd * sizeof(float)));
+        md = ctx->bnb_mindis.as<float>();
+    }
+    ICPX_TRY(bnb_enqueue(ctx, items, nitems, ctx->bnb_out.as<double>(), md));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ub, ctx->bnb_out.p, nitems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(lb, ctx->bnb_out.as<double>() + nitems, nitems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (mindis_opt)
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(mindis_opt, md, nitems * ctx->nd * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+extern "C" int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev) {
+    if (!ctx) return ICPX_EINVAL;
+    if (nitems == 0) return ICPX_OK;
+    if (!out_dev) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval_async: out_dev is NULL");
+    ICPX_TRY(icpx_bind(ctx));
+    return bnb_enqueue(ctx, items, nitems, out_dev, nullptr);
+}
+
+extern "C" int icpx_goicp_residuals(icpx_ctx* ctx, const double T[16], float* dist_out) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_goicp_residuals: no EDT has been built");
+    if (ctx->nd == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_goicp_residuals: no data cloud (call icpx_goicp_set_data first)");
+    if (!T || !dist_out) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_goicp_residuals: NULL argument");
+    ICPX_TRY(icpx_bind(ctx));
+    const size_t n = ctx->nd;
+    ICPX_TRY(icpx_reserve(ctx, ctx->bnb_mindis, n * sizeof(float)));
+    Mat34 M;
+    for (int k = 0; k < 12; k++) M.m[k] = T[k];
+    hipLaunchKernelGGL(k_goicp_residuals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, edt_view(ctx),
+                       ctx->data_pts.as<float4>(), n, M, ctx->bnb_mindis.as<float>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_goicp_residuals"));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(dist_out, ctx->bnb_mindis.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}

@@ -1,0 +1,113 @@
+// Internal context of the icpx library (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/icpx.h"
+
+// Grow-only device allocation.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct icpx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int num_cus = 256;
+
+    // ---- target cloud --------------------------------------------------------------------------
+    size_t nt = 0;
+    DevBuf tgt_xyz;          // nt x 3 float, caller order
+    float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};   // float bounding box of the target
+
+    // ---- uniform search grid over the target -----------------------------------------------------
+    bool grid_ready = false;
+    int gdim[3] = {0, 0, 0};
+    float gmin[3] = {0, 0, 0};
+    float gh = 0.f, ginv = 0.f;
+    DevBuf cell_range;       // ncells x int2 {first, last} into sorted_pts
+    DevBuf sorted_pts;       // nt x float4 {x, y, z, bits(original index)} sorted by cell, ties by index
+    DevBuf sort_keys_a, sort_keys_b, sort_vals_a, sort_vals_b, sort_tmp;
+
+    // ---- source cloud (ICP) ----------------------------------------------------------------------
+    size_t ns = 0;
+    DevBuf src_pts;          // ns x float4 {x, y, z, bits(original index)}, spatially sorted
+    DevBuf partials;         // per-block partial sums
+    DevBuf sums;             // ICPX_NSUMS doubles
+    DevBuf scratch_q, scratch_idx, scratch_d2, scratch_f;   // staging for host-pointer calls
+
+    // ---- EDT ---------------------------------------------------------------------------------------
+    bool edt_ready = false;
+    uint32_t div = 0;
+    int edt_words = 0;       // 64-bit words per (x,y) bit row
+    float edt_min[3] = {0, 0, 0};
+    float edt_cell = 0.f;
+    int edt_cap_zy = 64, edt_cap_x = 64;   // LDS stack levels per lane
+    DevBuf edt_bits;         // div*div*edt_words uint64 occupancy bits
+    DevBuf edt_rowlist;      // div x div uint16: ascending non-empty rows y of every plane x
+    DevBuf edt_rowcnt;       // div int
+    DevBuf edt_planelist;    // div uint16 ascending non-empty planes; [div] holds nothing
+    DevBuf edt_counters;     // uint64 x 4: {occupied voxels, dropped points, nplanes, unused}
+    DevBuf edt_plane;        // div^3 int32: in-plane squared distances (only non-empty planes written)
+    DevBuf edt_sq;           // div^3 int32: squared EDT, [x][y][z]
+
+    // ---- Go-ICP ---------------------------------------------------------------------------------------
+    size_t nd = 0;
+    DevBuf data_pts;         // nd x float4 {x, y, z, bits(original index)}, spatially sorted
+    DevBuf maxrot;           // ICPX_MAXROTLEVEL x nd float, sorted order
+    DevBuf bnb_items, bnb_partials, bnb_out, bnb_mindis;
+
+    void set_error(const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+    }
+};
+
+#define ICPX_CHECK_HIP(ctx, call)                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? ICPX_ENOMEM : ICPX_EHIP;                        \
+        }                                                                                      \
+    } while (0)
+
+#define ICPX_TRY(expr)                 \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != ICPX_OK) return rc_; \
+    } while (0)
+
+#define ICPX_FAIL(ctx, code, ...)       \
+    do {                               \
+        (ctx)->set_error(__VA_ARGS__); \
+        return (code);                 \
+    } while (0)
+
+// icpx_api.hip
+int icpx_reserve(icpx_ctx* ctx, DevBuf& b, size_t bytes);
+int icpx_bind(icpx_ctx* ctx);   // hipSetDevice(ctx->device)
+int icpx_launch_check(icpx_ctx* ctx, const char* what);
+// Packs `n` points of 3 floats at `stride_bytes` (host or device) into a device float4 array
+// {x, y, z, bits(i)} in caller order; dst must hold n float4.
+int icpx_stage_points4(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, int where, float4* dst);
+// Sorts float4 points (w = original index bits) by a 30-bit Morton code over their own bounding box.
+int icpx_morton_sort4(icpx_ctx* ctx, float4* pts, size_t n);
+
+// icpx_nn.hip
+int icpx_grid_build(icpx_ctx* ctx);
+// icpx_edt.hip
+int icpx_edt_run(icpx_ctx* ctx);

@@ -1,0 +1,374 @@
+// Exact squared Euclidean distance transform on a div^3 voxel grid, and its lookup.
+//
+// Stands in for LDT::LDT and LDT::Distance of the reference (src/testLDT.cpp:40-212, :235-290).
+// The result is the grid the reference's three passes compute before the final sqrt (with the y-pass
+// scan-back comparing y against t[q], as its x pass does at :197-202), i.e. the exact squared EDT of
+// the occupied voxels in cell units.
+//
+// Pipeline (all on one stream):
+//   splat    points -> occupancy bits (one bit per voxel, 64-bit words along z)      src/testLDT.cpp:74-88
+//   census   per plane x: ascending list of rows y that hold any occupied voxel; list of non-empty planes
+//   pass zy  per plane x and 64-wide z chunk (one lane per z): distance along z from the bit row
+//            (:91-109), then the lower envelope along y (:123-157); rows without voxels never win the
+//            envelope, so only listed rows are scanned
+//   pass x   per y and z chunk: lower envelope along x over the non-empty planes, writes the final
+//            squared grid (:172-206 before the sqrt)
+// Memory traffic: the only full-size arrays are the in-plane distances (written for non-empty planes,
+// read once) and the output; the occupancy is 1 bit per voxel and stays in L2.
+//
+// Envelope stacks: one lane owns one grid row; its stack of (site, start, value) entries lives in LDS
+// for the first `cap` levels ([level][lane], conflict-free) and, beyond that, in the lane's own
+// not-yet-written output slots (slot `level` of the row), which the scan-back has not reached when it
+// reads them back (level <= start[level] <= current position).
+#include "icpx_ctx.h"
+#include "icpx_edt_dev.h"
+
+typedef unsigned long long u64;
+
+namespace {
+
+constexpr int BIGD = 1 << 20;
+
+// ---- splat ------------------------------------------------------------------------------------------
+__global__ void k_edt_splat(const float* __restrict__ pts, size_t n, float mnx, float mny, float mnz, float cell, int div,
+                            int W, u64* __restrict__ bits, u64* __restrict__ counters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // float subtract, float divide (round to nearest), truncate: src/testLDT.cpp:78-80
+    int ix = (int)__fdiv_rn(__fsub_rn(pts[3 * i], mnx), cell);
+    int iy = (int)__fdiv_rn(__fsub_rn(pts[3 * i + 1], mny), cell);
+    int iz = (int)__fdiv_rn(__fsub_rn(pts[3 * i + 2], mnz), cell);
+    if (ix < 0 || iy < 0 || iz < 0 || ix >= div || iy >= div || iz >= div) {
+        atomicAdd(&counters[1], 1ull);
+        return;
+    }
+    atomicOr(&bits[((size_t)ix * div + iy) * W + (iz >> 6)], 1ull << (iz & 63));
+}
+
+// ---- census: one wave per plane x ------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_edt_census(const u64* __restrict__ bits, int div, int W, unsigned short* __restrict__ rowlist,
+                                                   int* __restrict__ rowcnt, u64* __restrict__ counters) {
+    const int x = blockIdx.x, lane = threadIdx.x;
+    int cnt = 0;
+    unsigned occ = 0;
+    for (int base = 0; base < div; base += 64) {
+        const int y = base + lane;
+        bool any = false;
+        if (y < div) {
+            const u64* row = bits + ((size_t)x * div + y) * W;
+            for (int w = 0; w < W; w++) { u64 v = row[w]; any |= v != 0; occ += __popcll(v); }
+        }
+        const u64 m = __ballot(any);
+        if (any) rowlist[(size_t)x * div + cnt + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)y;
+        cnt += __popcll(m);
+    }
+    for (int o = 32; o > 0; o >>= 1) occ += __shfl_xor(occ, o);
+    if (lane == 0) {
+        rowcnt[x] = cnt;
+        if (occ) atomicAdd(&counters[0], (u64)occ);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_edt_planes(const int* __restrict__ rowcnt, int div, unsigned short* __restrict__ planelist,
+                                                   u64* __restrict__ counters) {
+    const int lane = threadIdx.x;
+    int cnt = 0;
+    for (int base = 0; base < div; base += 64) {
+        const int x = base + lane;
+        const bool any = x < div && rowcnt[x] > 0;
+        const u64 m = __ballot(any);
+        if (any) planelist[cnt + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)x;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) counters[2] = (u64)cnt;
+}
+
+// floor(N / D) for 0 <= N < 2^23, 1 <= D < 2^12 via a float reciprocal and one correction step.
+__device__ __forceinline__ int floordiv_pos(int N, int D) {
+    int k = (int)((float)N * __builtin_amdgcn_rcpf((float)D));
+    int r = N - k * D;
+    if (r < 0) { k--; r += D; }
+    if (r < 0) { k--; r += D; }
+    if (r >= D) { k++; r -= D; }
+    if (r >= D) k++;
+    return k;
+}
+
+// ---- pass zy ------------------------------------------------------------------------------------------
+// Entry packing for this pass: site (10 bits) | start (10 bits) | distance along z (10 bits).
+__global__ __launch_bounds__(64) void k_edt_pass_zy(const u64* __restrict__ bits, const unsigned short* __restrict__ rowlist,
+                                                    const int* __restrict__ rowcnt, int* __restrict__ plane, int div, int W,
+                                                    int nchunk, int cap) {
+    extern __shared__ unsigned lds[];   // [cap][64]
+    const int x = blockIdx.x / nchunk, c = blockIdx.x % nchunk;
+    const int cnt = rowcnt[x];
+    if (cnt == 0) return;   // plane without voxels: never read by pass x
+    const int lane = threadIdx.x, z = c * 64 + lane;
+    if (z >= div) return;
+    const size_t rowstride = (size_t)div;                 // elements between consecutive y
+    int* out = plane + (size_t)x * div * div + z;        // out[y * div]
+
+    int q = -1, ts = 0, tt = 0, tg = 0;   // cached top entry
+    const unsigned short* rl = rowlist + (size_t)x * div;
+    for (int k = 0; k < cnt; k++) {
+        const int u = rl[k];
+        const u64* row = bits + ((size_t)x * div + u) * W;
+        // distance along z to the nearest set bit of this row (the row has at least one)
+        int below = -BIGD, above = BIGD;                 // wave-uniform: nearest set bit in other words
+        for (int j = c - 1; j >= 0; j--) { u64 v = row[j]; if (v) { below = 64 * j + 63 - __clzll(v); break; } }
+        for (int j = c + 1; j < W; j++) { u64 v = row[j]; if (v) { above = 64 * j + (__ffsll((long long)v) - 1); break; } }
+        const u64 own = row[c];
+        const u64 md = own & (~0ull >> (63 - lane));
+        const u64 mu = own >> lane;
+        const int down = md ? lane - (63 - __clzll(md)) : z - below;
+        const int up = mu ? (__ffsll((long long)mu) - 1) : above - z;
+        const int g = min(down, up);
+        const int Gu = g * g;
+
+        if (q >= 0) {
+            while (true) {
+                const int a = (tt - ts) * (tt - ts) + tg * tg;
+                const int b = (tt - u) * (tt - u) + Gu;
+                if (a <= b) break;
+                q--;
+                if (q < 0) break;
+                const unsigned e = q < cap ? lds[q * 64 + lane] : (unsigned)out[(size_t)q * rowstride];
+                ts = e & 1023; tt = (e >> 10) & 1023; tg = e >> 20;
+            }
+        }
+        bool push = false;
+        int w = 0;
+        if (q < 0) { q = 0; push = true; }
+        else {
+            w = 1 + floordiv_pos(u * u - ts * ts + Gu - tg * tg, 2 * (u - ts));
+            if (w < div) { q++; push = true; }
+        }
+        if (push) {
+            ts = u; tt = w; tg = g;
+            const unsigned e = (unsigned)u | ((unsigned)w << 10) | ((unsigned)g << 20);
+            if (q < cap) lds[q * 64 + lane] = e; else out[(size_t)q * rowstride] = (int)e;
+        }
+    }
+    for (int y = div - 1; y >= 0; y--) {
+        const int v = (y - ts) * (y - ts) + tg * tg;
+        unsigned e = 0;
+        const bool pop = (y == tt) && q > 0;
+        if (pop) { q--; e = q < cap ? lds[q * 64 + lane] : (unsigned)out[(size_t)q * rowstride]; }
+        out[(size_t)y * rowstride] = v;
+        if (pop) { ts = e & 1023; tt = (e >> 10) & 1023; tg = e >> 20; }
+    }
+}
+
+// ---- pass x ---------------------------------------------------------------------------------------------
+// Entries: LDS holds {site | start << 16, value}; spilled levels keep site/start in the output slot and
+// re-read the value from the in-plane array.
+__global__ __launch_bounds__(64) void k_edt_pass_x(const int* __restrict__ plane, const unsigned short* __restrict__ planelist,
+                                                   const u64* __restrict__ counters, int* __restrict__ sq, int div, int nchunk,
+                                                   int cap) {
+    extern __shared__ unsigned lds[];   // [cap][64] site/start, then [cap][64] value
+    unsigned* lds_v = lds + cap * 64;
+    const int y = blockIdx.x / nchunk, c = blockIdx.x % nchunk;
+    const int lane = threadIdx.x, z = c * 64 + lane;
+    if (z >= div) return;
+    const int np = (int)counters[2];
+    const size_t xs = (size_t)div * div;                  // elements between consecutive x
+    const int* in = plane + (size_t)y * div + z;          // in[u * xs]
+    int* out = sq + (size_t)y * div + z;                  // out[x * xs]
+
+    int q = -1, ts = 0, tt = 0, tG = 0;
+    int Gnext = np > 0 ? in[(size_t)planelist[0] * xs] : 0;
+    for (int k = 0; k < np; k++) {
+        const int u = planelist[k];
+        const int Gu = Gnext;
+        if (k + 1 < np) Gnext = in[(size_t)planelist[k + 1] * xs];
+        if (q >= 0) {
+            while (true) {
+                const int a = (tt - ts) * (tt - ts) + tG;
+                const int b = (tt - u) * (tt - u) + Gu;
+                if (a <= b) break;
+                q--;
+                if (q < 0) break;
+                if (q < cap) { const unsigned e = lds[q * 64 + lane]; ts = e & 0xffff; tt = e >> 16; tG = (int)lds_v[q * 64 + lane]; }
+                else { const unsigned e = (unsigned)out[(size_t)q * xs]; ts = e & 0xffff; tt = e >> 16; tG = in[(size_t)ts * xs]; }
+            }
+        }
+        bool push = false;
+        int w = 0;
+        if (q < 0) { q = 0; push = true; }
+        else {
+            w = 1 + floordiv_pos(u * u - ts * ts + Gu - tG, 2 * (u - ts));
+            if (w < div) { q++; push = true; }
+        }
+        if (push) {
+            ts = u; tt = w; tG = Gu;
+            const unsigned e = (unsigned)u | ((unsigned)w << 16);
+            if (q < cap) { lds[q * 64 + lane] = e; lds_v[q * 64 + lane] = (unsigned)Gu; }
+            else out[(size_t)q * xs] = (int)e;
+        }
+    }
+    for (int x = div - 1; x >= 0; x--) {
+        const int v = (x - ts) * (x - ts) + tG;
+        const bool pop = (x == tt) && q > 0;
+        int ns = 0, nt = 0, nG = 0;
+        if (pop) {
+            q--;
+            if (q < cap) { const unsigned e = lds[q * 64 + lane]; ns = e & 0xffff; nt = e >> 16; nG = (int)lds_v[q * 64 + lane]; }
+            else { const unsigned e = (unsigned)out[(size_t)q * xs]; ns = e & 0xffff; nt = e >> 16; nG = in[(size_t)ns * xs]; }
+        }
+        out[(size_t)x * xs] = v;
+        if (pop) { ts = ns; tt = nt; tG = nG; }
+    }
+}
+
+// ---- lookup (device function in icpx_edt_dev.h) ----
+__global__ void k_edt_lookup(const int* __restrict__ sq, int div, float mnx, float mny, float mnz, float cell,
+                             const float* __restrict__ q, size_t n, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = edt_distance(sq, div, mnx, mny, mnz, cell, q[3 * i], q[3 * i + 1], q[3 * i + 2]);
+}
+
+}  // namespace
+
+int icpx_edt_run(icpx_ctx* ctx) {
+    const int div = (int)ctx->div, W = ctx->edt_words;
+    const int nchunk = (div + 63) / 64;
+    hipStream_t s = ctx->stream;
+    ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_bits.p, 0, (size_t)div * div * W * sizeof(u64), s));
+    ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_counters.p, 0, 4 * sizeof(u64), s));
+    hipLaunchKernelGGL(k_edt_splat, dim3((unsigned)((ctx->nt + 255) / 256)), dim3(256), 0, s, ctx->tgt_xyz.as<float>(), ctx->nt,
+                       ctx->edt_min[0], ctx->edt_min[1], ctx->edt_min[2], ctx->edt_cell, div, W, ctx->edt_bits.as<u64>(),
+                       ctx->edt_counters.as<u64>());
+    hipLaunchKernelGGL(k_edt_census, dim3(div), dim3(64), 0, s, ctx->edt_bits.as<u64>(), div, W, ctx->edt_rowlist.as<unsigned short>(),
+                       ctx->edt_rowcnt.as<int>(), ctx->edt_counters.as<u64>());
+    hipLaunchKernelGGL(k_edt_planes, dim3(1), dim3(64), 0, s, ctx->edt_rowcnt.as<int>(), div, ctx->edt_planelist.as<unsigned short>(),
+                       ctx->edt_counters.as<u64>());
+    hipLaunchKernelGGL(k_edt_pass_zy, dim3(div * nchunk), dim3(64), (size_t)ctx->edt_cap_zy * 64 * 4, s, ctx->edt_bits.as<u64>(),
+                       ctx->edt_rowlist.as<unsigned short>(), ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), div, W, nchunk,
+                       ctx->edt_cap_zy);
+    hipLaunchKernelGGL(k_edt_pass_x, dim3(div * nchunk), dim3(64), (size_t)ctx->edt_cap_x * 64 * 8, s, ctx->edt_plane.as<int>(),
+                       ctx->edt_planelist.as<unsigned short>(), ctx->edt_counters.as<u64>(), ctx->edt_sq.as<int>(), div, nchunk,
+                       ctx->edt_cap_x);
+    return icpx_launch_check(ctx, "EDT kernels");
+}
+
+static int edt_prepare(icpx_ctx* ctx, uint32_t div) {
+    if (ctx->nt == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "EDT build: no target cloud (call icpx_set_target first)");
+    if (div < 2 || div > ICPX_MAX_DIV) ICPX_FAIL(ctx, ICPX_ELIMIT, "EDT build: div must be in [2, %d]", ICPX_MAX_DIV);
+    ICPX_TRY(icpx_bind(ctx));
+    ctx->edt_ready = false;
+    ctx->div = div;
+    ctx->edt_words = (int)((div + 63) / 64);
+    const size_t n3 = (size_t)div * div * div;
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_bits, (size_t)div * div * ctx->edt_words * sizeof(u64)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_rowlist, (size_t)div * div * sizeof(unsigned short)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_rowcnt, (size_t)div * sizeof(int)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_planelist, (size_t)(div + 1) * sizeof(unsigned short)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_counters, 4 * sizeof(u64)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_plane, n3 * sizeof(int)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_sq, n3 * sizeof(int)));
+    return ICPX_OK;
+}
+
+extern "C" int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[3], float cell_len) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!min3 || !(cell_len > 0.f)) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_build_box: bad box");
+    ICPX_TRY(edt_prepare(ctx, div));
+    ctx->edt_min[0] = min3[0]; ctx->edt_min[1] = min3[1]; ctx->edt_min[2] = min3[2];
+    ctx->edt_cell = cell_len;
+    ICPX_TRY(icpx_edt_run(ctx));
+    u64 counters[4];
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, ctx->edt_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (counters[0] == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "EDT build: no target point falls inside the grid");
+    ctx->edt_ready = true;
+    return ICPX_OK;
+}
+
+extern "C" int icpx_edt_build(icpx_ctx* ctx, uint32_t div) {
+    if (!ctx) return ICPX_EINVAL;
+    if (ctx->nt == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_build: no target cloud (call icpx_set_target first)");
+    if (div < 2) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_edt_build: div must be >= 2");
+    // Box rule of src/testLDT.cpp:54-68 with its arithmetic types: float diagonal, largest extent * 1.1
+    // in double, float mid-point, expansion factor 2, cell length rounded to float.
+    const float* mn = ctx->bbmin; const float* mx = ctx->bbmax;
+    const float d0 = mx[0] - mn[0], d1 = mx[1] - mn[1], d2 = mx[2] - mn[2];
+    const float m01 = d0 < d1 ? d1 : d0;
+    const float m = m01 < d2 ? d2 : m01;
+    double fullLen = (double)m * 1.1;
+    const double halfLen = fullLen / 2;
+    float lo[3];
+    for (int c = 0; c < 3; c++) {
+        const float mid = (mn[c] + mx[c]) / 2.0f;
+        lo[c] = (float)((double)mid - halfLen * 2.0);
+    }
+    fullLen = 2 * halfLen * 2.0;
+    const float cell = (float)(fullLen / (double)(float)div);
+    if (!(cell > 0.f)) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_build: degenerate target bounding box");
+    return icpx_edt_build_box(ctx, div, lo, cell);
+}
+
+extern "C" int icpx_edt_rebuild_async(icpx_ctx* ctx) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_rebuild_async: no EDT has been built yet");
+    ICPX_TRY(icpx_bind(ctx));
+    return icpx_edt_run(ctx);
+}
+
+extern "C" int icpx_edt_info(icpx_ctx* ctx, uint32_t* div, float min3[3], float* cell_len, uint64_t* occupied, uint64_t* dropped) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_info: no EDT has been built");
+    ICPX_TRY(icpx_bind(ctx));
+    if (div) *div = ctx->div;
+    if (min3) { min3[0] = ctx->edt_min[0]; min3[1] = ctx->edt_min[1]; min3[2] = ctx->edt_min[2]; }
+    if (cell_len) *cell_len = ctx->edt_cell;
+    if (occupied || dropped) {
+        u64 counters[4];
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, ctx->edt_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
+        ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (occupied) *occupied = counters[0];
+        if (dropped) *dropped = counters[1];
+    }
+    return ICPX_OK;
+}
+
+extern "C" int icpx_edt_read(icpx_ctx* ctx, int32_t* sq_out, int where) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_read: no EDT has been built");
+    if (!sq_out) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_read: output is NULL");
+    ICPX_TRY(icpx_bind(ctx));
+    const size_t bytes = (size_t)ctx->div * ctx->div * ctx->div * sizeof(int);
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sq_out, ctx->edt_sq.p, bytes, where == ICPX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                       ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+extern "C" int icpx_edt_grid_ptr(icpx_ctx* ctx, const int32_t** sq_dev) {
+    if (!ctx || !sq_dev) return ICPX_EINVAL;
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_grid_ptr: no EDT has been built");
+    *sq_dev = ctx->edt_sq.as<int32_t>();
+    return ICPX_OK;
+}
+
+extern "C" int icpx_edt_lookup(icpx_ctx* ctx, const float* xyz, size_t n, int where, float* dist) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_lookup: no EDT has been built");
+    if (n == 0) return ICPX_OK;
+    if (!xyz || !dist) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_lookup: NULL buffer");
+    ICPX_TRY(icpx_bind(ctx));
+    const float* dq = xyz; float* dout = dist;
+    if (where == ICPX_HOST) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->scratch_q, n * 3 * sizeof(float)));
+        ICPX_TRY(icpx_reserve(ctx, ctx->scratch_d2, n * sizeof(float)));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        dq = ctx->scratch_q.as<float>(); dout = ctx->scratch_d2.as<float>();
+    }
+    hipLaunchKernelGGL(k_edt_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->edt_sq.as<int>(), (int)ctx->div,
+                       ctx->edt_min[0], ctx->edt_min[1], ctx->edt_min[2], ctx->edt_cell, dq, n, dout);
+    ICPX_TRY(icpx_launch_check(ctx, "k_edt_lookup"));
+    if (where == ICPX_HOST)
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(dist, dout, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}

@@ -1,0 +1,374 @@
+// Uniform-grid nearest-neighbour search and the fused ICP iteration kernel.
+//
+// Stands in for the reference's kd-tree (src/kdtree.cpp:58-150) and for the per-iteration loops of
+// SingleThreadIcp (kdtree_search src/SingleThreadIcp.cpp:186-214, cal_covarance :216-247, the residual
+// of best_fit_transform :281-287). Results are exact: every candidate distance is the reference's
+// double-precision expression ((dx*dx + dy*dy) + dz*dz) without fused multiply-add (this file is built
+// with -ffp-contract=off), ties resolve to the lowest target index, and cells / rings are skipped only
+// when a conservative lower bound on their distance is strictly larger than the best distance so far.
+//
+// Layout: target points sorted by cell (stable, so ascending original index inside a cell) as
+// float4 {x, y, z, bits(index)}; cell_range[cell] = {first, last}. Queries of the ICP step are the
+// source cloud in Morton order, so neighbouring lanes walk neighbouring cells.
+#include "icpx_ctx.h"
+
+#include <cfloat>
+#include <cmath>
+
+int icpx_sort_pairs(icpx_ctx* ctx, size_t n, unsigned end_bit);
+int icpx_sort_reserve(icpx_ctx* ctx, size_t n);
+
+namespace {
+
+struct GridView {
+    int dx, dy, dz;
+    float minx, miny, minz, h, inv;
+    const int2* __restrict__ range;
+    const float4* __restrict__ pts;
+};
+
+__device__ __forceinline__ int cell_coord(float v, float mn, float inv, int dim) {
+    const float f = floorf((v - mn) * inv);
+    return (int)fminf(fmaxf(f, 0.f), (float)(dim - 1));
+}
+
+__global__ void k_cell_keys(const float4* __restrict__ pts, size_t n, GridView g, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const int cx = cell_coord(p.x, g.minx, g.inv, g.dx), cy = cell_coord(p.y, g.miny, g.inv, g.dy), cz = cell_coord(p.z, g.minz, g.inv, g.dz);
+    keys[i] = (unsigned)((cx * g.dy + cy) * g.dz + cz);
+    vals[i] = (unsigned)i;
+}
+
+__global__ void k_cell_ranges(const unsigned* __restrict__ keys, size_t n, int2* __restrict__ range, unsigned* __restrict__ distinct) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned k = keys[i];
+    if (i == 0 || keys[i - 1] != k) { range[k].x = (int)i; if (distinct) atomicAdd(distinct, 1u); }
+    if (i == n - 1 || keys[i + 1] != k) range[k].y = (int)(i + 1);
+}
+
+__global__ void k_gather_pts(const float4* __restrict__ src, const unsigned* __restrict__ order, size_t n, float4* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[order[i]];
+}
+
+struct Best {
+    double d2;
+    int idx;
+};
+
+__device__ __forceinline__ void scan_cell(const GridView& g, int cell, double qx, double qy, double qz, Best& b) {
+    const int2 r = g.range[cell];
+    for (int k = r.x; k < r.y; k++) {
+        const float4 p = g.pts[k];
+        const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+        const double d = (dx * dx + dy * dy) + dz * dz;
+        const int id = __float_as_int(p.w);
+        if (d < b.d2 || (d == b.d2 && id < b.idx)) { b.d2 = d; b.idx = id; }
+    }
+}
+
+// Distance from coordinate q to the interval [lo, hi], shrunk by `margin`, squared; 0 inside.
+__device__ __forceinline__ double axis_gap2(double q, double lo, double hi, double margin) {
+    double g = fmax(fmax(lo - q, q - hi) - margin, 0.0);
+    return g * g;
+}
+
+__device__ Best nn_search(const GridView& g, double qx, double qy, double qz) {
+    Best b{INFINITY, 0x7fffffff};
+    const int cx = cell_coord((float)qx, g.minx, g.inv, g.dx), cy = cell_coord((float)qy, g.miny, g.inv, g.dy),
+              cz = cell_coord((float)qz, g.minz, g.inv, g.dz);
+    scan_cell(g, (cx * g.dy + cy) * g.dz + cz, qx, qy, qz, b);
+    const double h = (double)g.h;
+    // Cell membership of the target points was decided in float arithmetic: a point can sit up to a few
+    // float ulps outside the box of its cell. The margin makes every lower bound conservative.
+    const double margin = 1e-3 * h + 1e-6 * (fabs(qx) + fabs(qy) + fabs(qz));
+    const double ox = (double)g.minx, oy = (double)g.miny, oz = (double)g.minz;
+    const int rmax = max(max(max(cx, g.dx - 1 - cx), max(cy, g.dy - 1 - cy)), max(cz, g.dz - 1 - cz));
+    const double bx = fmax(fmax(ox - qx, qx - (ox + g.dx * h)) - margin, 0.0);
+    const double by = fmax(fmax(oy - qy, qy - (oy + g.dy * h)) - margin, 0.0);
+    const double bz = fmax(fmax(oz - qz, qz - (oz + g.dz * h)) - margin, 0.0);
+    for (int r = 1; r <= rmax; r++) {
+        // Lower bound over everything at Chebyshev cell distance >= r: the nearest of the six slabs.
+        // Each slab bound is combined with the distance to the grid's own box along the other two axes
+        // (bx, by, bz), which matters for queries outside the grid.
+        double ring = INFINITY;
+        if (cx + r < g.dx) { double t = fmax(fmax(ox + (cx + r) * h - qx - margin, 0.0), bx); ring = fmin(ring, t * t + by * by + bz * bz); }
+        if (cx - r >= 0)   { double t = fmax(fmax(qx - (ox + (cx - r + 1) * h) - margin, 0.0), bx); ring = fmin(ring, t * t + by * by + bz * bz); }
+        if (cy + r < g.dy) { double t = fmax(fmax(oy + (cy + r) * h - qy - margin, 0.0), by); ring = fmin(ring, bx * bx + t * t + bz * bz); }
+        if (cy - r >= 0)   { double t = fmax(fmax(qy - (oy + (cy - r + 1) * h) - margin, 0.0), by); ring = fmin(ring, bx * bx + t * t + bz * bz); }
+        if (cz + r < g.dz) { double t = fmax(fmax(oz + (cz + r) * h - qz - margin, 0.0), bz); ring = fmin(ring, bx * bx + by * by + t * t); }
+        if (cz - r >= 0)   { double t = fmax(fmax(qz - (oz + (cz - r + 1) * h) - margin, 0.0), bz); ring = fmin(ring, bx * bx + by * by + t * t); }
+        if (ring > b.d2) break;
+        const int i0 = max(cx - r, 0), i1 = min(cx + r, g.dx - 1);
+        const int j0 = max(cy - r, 0), j1 = min(cy + r, g.dy - 1);
+        const int k0 = max(cz - r, 0), k1 = min(cz + r, g.dz - 1);
+        for (int i = i0; i <= i1; i++) {
+            const double gx = axis_gap2(qx, ox + i * h, ox + (i + 1) * h, margin);
+            if (gx > b.d2) continue;
+            const bool edge_i = (i == cx - r) || (i == cx + r);
+            for (int j = j0; j <= j1; j++) {
+                const double gxy = gx + axis_gap2(qy, oy + j * h, oy + (j + 1) * h, margin);
+                if (gxy > b.d2) continue;
+                const bool shell = edge_i || (j == cy - r) || (j == cy + r);
+                const int row = (i * g.dy + j) * g.dz;
+                if (shell) {
+                    for (int k = k0; k <= k1; k++) {
+                        if (gxy + axis_gap2(qz, oz + k * h, oz + (k + 1) * h, margin) > b.d2) continue;
+                        scan_cell(g, row + k, qx, qy, qz, b);
+                    }
+                } else {
+                    if (cz - r >= 0 && !(gxy + axis_gap2(qz, oz + (cz - r) * h, oz + (cz - r + 1) * h, margin) > b.d2))
+                        scan_cell(g, row + cz - r, qx, qy, qz, b);
+                    if (cz + r < g.dz && !(gxy + axis_gap2(qz, oz + (cz + r) * h, oz + (cz + r + 1) * h, margin) > b.d2))
+                        scan_cell(g, row + cz + r, qx, qy, qz, b);
+                }
+            }
+        }
+    }
+    return b;
+}
+
+__global__ __launch_bounds__(256) void k_nn(GridView g, const double* __restrict__ q, size_t n, int* __restrict__ idx, double* __restrict__ d2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Best b = nn_search(g, q[3 * i], q[3 * i + 1], q[3 * i + 2]);
+    if (idx) idx[i] = b.idx;
+    if (d2) d2[i] = b.d2;
+}
+
+__global__ __launch_bounds__(256) void k_nn_distance(GridView g, const float* __restrict__ q, size_t n, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Best b = nn_search(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2]);
+    out[i] = (float)__dsqrt_rn(b.d2);
+}
+
+struct Mat34 { double m[12]; };
+
+// One ICP pass: p = T * [src;1] (multiply then add, k = 0..3 from a zero accumulator), nearest target
+// point q, and block-partial sums {p, q, p q^T, |p-q|^2}.
+__global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __restrict__ src, size_t n, Mat34 T,
+                                                  const float* __restrict__ tgt_xyz, double* __restrict__ partials,
+                                                  int* __restrict__ idx_out) {
+    double acc[ICPX_NSUMS];
+#pragma unroll
+    for (int k = 0; k < ICPX_NSUMS; k++) acc[k] = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 s = src[i];
+        double p[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            double a = 0.0;
+            a += T.m[4 * r + 0] * (double)s.x;
+            a += T.m[4 * r + 1] * (double)s.y;
+            a += T.m[4 * r + 2] * (double)s.z;
+            a += T.m[4 * r + 3];
+            p[r] = a;
+        }
+        const Best b = nn_search(g, p[0], p[1], p[2]);
+        if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
+        const double q0 = (double)tgt_xyz[3 * (size_t)b.idx], q1 = (double)tgt_xyz[3 * (size_t)b.idx + 1], q2 = (double)tgt_xyz[3 * (size_t)b.idx + 2];
+        acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
+        acc[3] += q0; acc[4] += q1; acc[5] += q2;
+        acc[6] += p[0] * q0; acc[7] += p[0] * q1; acc[8] += p[0] * q2;
+        acc[9] += p[1] * q0; acc[10] += p[1] * q1; acc[11] += p[1] * q2;
+        acc[12] += p[2] * q0; acc[13] += p[2] * q1; acc[14] += p[2] * q2;
+        acc[15] += b.d2;
+    }
+    __shared__ double sm[4][ICPX_NSUMS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < ICPX_NSUMS; k++) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) sm[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICPX_NSUMS)
+        partials[(size_t)blockIdx.x * ICPX_NSUMS + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// Fixed-order final reduction of the block partials: thread t sums component t%16 of blocks t/16, t/16+64, ...
+__global__ __launch_bounds__(1024) void k_reduce_sums(const double* __restrict__ partials, int nblocks, double* __restrict__ sums) {
+    __shared__ double sm[1024];
+    const int comp = threadIdx.x & 15, lanegrp = threadIdx.x >> 4;
+    double v = 0.0;
+    for (int b = lanegrp; b < nblocks; b += 64) v += partials[(size_t)b * ICPX_NSUMS + comp];
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+        if (lanegrp < s) sm[threadIdx.x] += sm[threadIdx.x + s * 16];
+        __syncthreads();
+    }
+    if (threadIdx.x < ICPX_NSUMS) sums[threadIdx.x] = sm[threadIdx.x];
+}
+
+GridView view_of(const icpx_ctx* ctx) {
+    GridView g;
+    g.dx = ctx->gdim[0]; g.dy = ctx->gdim[1]; g.dz = ctx->gdim[2];
+    g.minx = ctx->gmin[0]; g.miny = ctx->gmin[1]; g.minz = ctx->gmin[2];
+    g.h = ctx->gh; g.inv = ctx->ginv;
+    g.range = ctx->cell_range.as<int2>();
+    g.pts = ctx->sorted_pts.as<float4>();
+    return g;
+}
+
+}  // namespace
+
+// Builds the search grid over the staged target (ctx->sorted_pts holds the points in caller order).
+// Cell size: start from one point per cell by volume, then — point sets sampled from surfaces fill far
+// fewer cells than that — refine once so that an occupied cell holds about four points.
+int icpx_grid_build(icpx_ctx* ctx) {
+    const size_t n = ctx->nt;
+    const double ext[3] = {(double)ctx->bbmax[0] - ctx->bbmin[0], (double)ctx->bbmax[1] - ctx->bbmin[1], (double)ctx->bbmax[2] - ctx->bbmin[2]};
+    const double emax = std::max(ext[0], std::max(ext[1], ext[2]));
+    const double floor_e = emax > 0 ? emax * 1e-3 : 1.0;   // degenerate (flat) extents still get one cell
+    double vol = 1.0;
+    for (int c = 0; c < 3; c++) vol *= std::max(ext[c], floor_e);
+    double h = std::cbrt(vol / (double)n);
+    const double max_cells = 3.2e7;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    ICPX_TRY(icpx_sort_reserve(ctx, n));
+    ICPX_TRY(icpx_reserve(ctx, ctx->scratch_q, n * sizeof(float4)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_counters, 4 * sizeof(unsigned long long)));
+    // keep the caller-order copy; sorted_pts is rewritten by the gather
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, ctx->sorted_pts.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int dim[3];
+        for (;;) {
+            double cells = 1.0;
+            for (int c = 0; c < 3; c++) { dim[c] = (int)std::min(1024.0, std::floor(ext[c] / h) + 1.0); cells *= dim[c]; }
+            if (cells <= max_cells) break;
+            h *= 1.26;
+        }
+        ctx->gh = (float)h; ctx->ginv = 1.0f / ctx->gh;
+        for (int c = 0; c < 3; c++) { ctx->gdim[c] = dim[c]; ctx->gmin[c] = ctx->bbmin[c]; }
+        const size_t ncells = (size_t)dim[0] * dim[1] * dim[2];
+        ICPX_TRY(icpx_reserve(ctx, ctx->cell_range, ncells * sizeof(int2)));
+        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->cell_range.p, 0, ncells * sizeof(int2), ctx->stream));
+        unsigned* distinct = reinterpret_cast<unsigned*>(ctx->edt_counters.as<unsigned long long>() + 3);
+        ICPX_CHECK_HIP(ctx, hipMemsetAsync(distinct, 0, sizeof(unsigned), ctx->stream));
+        GridView g = view_of(ctx);
+        hipLaunchKernelGGL(k_cell_keys, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scratch_q.as<float4>(), n, g,
+                           ctx->sort_keys_a.as<unsigned>(), ctx->sort_vals_a.as<unsigned>());
+        ICPX_TRY(icpx_launch_check(ctx, "k_cell_keys"));
+        unsigned bits = 1;
+        while ((1ull << bits) < ncells) bits++;
+        ICPX_TRY(icpx_sort_pairs(ctx, n, bits));
+        hipLaunchKernelGGL(k_cell_ranges, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sort_keys_b.as<unsigned>(), n,
+                           ctx->cell_range.as<int2>(), distinct);
+        ICPX_TRY(icpx_launch_check(ctx, "k_cell_ranges"));
+        unsigned occupied = 0;
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(&occupied, distinct, sizeof occupied, hipMemcpyDeviceToHost, ctx->stream));
+        ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double per_cell = occupied ? (double)n / occupied : 1.0;
+        if (attempt == 0 && per_cell > 6.0) { h *= std::sqrt(4.0 / per_cell); continue; }
+        break;
+    }
+    hipLaunchKernelGGL(k_gather_pts, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scratch_q.as<float4>(), ctx->sort_vals_b.as<unsigned>(), n,
+                       ctx->sorted_pts.as<float4>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_gather_pts"));
+    ctx->grid_ready = true;
+    return ICPX_OK;
+}
+
+extern "C" int icpx_nn(icpx_ctx* ctx, const double* q_xyz, size_t n, int where, int32_t* idx, double* d2) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->grid_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_nn: no target cloud (call icpx_set_target first)");
+    if (n == 0) return ICPX_OK;
+    if (!q_xyz) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_nn: queries are NULL");
+    ICPX_TRY(icpx_bind(ctx));
+    const double* dq = q_xyz; int* didx = idx; double* dd2 = d2;
+    if (where == ICPX_HOST) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->scratch_q, n * 3 * sizeof(double)));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, q_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        dq = ctx->scratch_q.as<double>();
+        if (idx) { ICPX_TRY(icpx_reserve(ctx, ctx->scratch_idx, n * sizeof(int))); didx = ctx->scratch_idx.as<int>(); }
+        if (d2) { ICPX_TRY(icpx_reserve(ctx, ctx->scratch_d2, n * sizeof(double))); dd2 = ctx->scratch_d2.as<double>(); }
+    }
+    hipLaunchKernelGGL(k_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, view_of(ctx), dq, n, didx, dd2);
+    ICPX_TRY(icpx_launch_check(ctx, "k_nn"));
+    if (where == ICPX_HOST) {
+        if (idx) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(idx, didx, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        if (d2) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(d2, dd2, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+extern "C" int icpx_nn_distance(icpx_ctx* ctx, const float* q_xyz, size_t n, int where, float* dist) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->grid_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_nn_distance: no target cloud (call icpx_set_target first)");
+    if (n == 0) return ICPX_OK;
+    if (!q_xyz || !dist) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_nn_distance: NULL buffer");
+    ICPX_TRY(icpx_bind(ctx));
+    const float* dq = q_xyz; float* dout = dist;
+    if (where == ICPX_HOST) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->scratch_q, n * 3 * sizeof(float)));
+        ICPX_TRY(icpx_reserve(ctx, ctx->scratch_d2, n * sizeof(float)));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, q_xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        dq = ctx->scratch_q.as<float>(); dout = ctx->scratch_d2.as<float>();
+    }
+    hipLaunchKernelGGL(k_nn_distance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, view_of(ctx), dq, n, dout);
+    ICPX_TRY(icpx_launch_check(ctx, "k_nn_distance"));
+    if (where == ICPX_HOST) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(dist, dout, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+extern "C" int icpx_set_source(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, int where) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!xyz || n == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_set_source: empty source cloud");
+    if (stride_bytes < 12 || stride_bytes % 4) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_set_source: stride must be a multiple of 4 and >= 12");
+    if (n > 0x7fffffffu) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_set_source: more than 2^31-1 points");
+    ICPX_TRY(icpx_bind(ctx));
+    ctx->ns = 0;
+    ICPX_TRY(icpx_reserve(ctx, ctx->src_pts, n * sizeof(float4)));
+    ICPX_TRY(icpx_stage_points4(ctx, xyz, n, stride_bytes, where, ctx->src_pts.as<float4>()));
+    ICPX_TRY(icpx_morton_sort4(ctx, ctx->src_pts.as<float4>(), n));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ns = n;
+    return ICPX_OK;
+}
+
+static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev, int* idx_dev) {
+    if (!ctx->grid_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_step: no target cloud (call icpx_set_target first)");
+    if (ctx->ns == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_step: no source cloud (call icpx_set_source first)");
+    if (!T) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_step: T is NULL");
+    const int blocks = (int)std::min<size_t>((ctx->ns + 255) / 256, (size_t)ctx->num_cus * 32);
+    ICPX_TRY(icpx_reserve(ctx, ctx->partials, (size_t)blocks * ICPX_NSUMS * sizeof(double)));
+    Mat34 M;
+    for (int k = 0; k < 12; k++) M.m[k] = T[k];
+    hipLaunchKernelGGL(k_icp_step, dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), ctx->src_pts.as<float4>(), ctx->ns, M,
+                       ctx->tgt_xyz.as<float>(), ctx->partials.as<double>(), idx_dev);
+    hipLaunchKernelGGL(k_reduce_sums, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, sums_dev);
+    return icpx_launch_check(ctx, "k_icp_step");
+}
+
+extern "C" int icpx_icp_step(icpx_ctx* ctx, const double T[16], double sums[ICPX_NSUMS], int32_t* idx_opt, int idx_where) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!sums) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_step: sums is NULL");
+    ICPX_TRY(icpx_bind(ctx));
+    ICPX_TRY(icpx_reserve(ctx, ctx->sums, ICPX_NSUMS * sizeof(double)));
+    int* didx = nullptr;
+    if (idx_opt) {
+        if (idx_where == ICPX_DEVICE) didx = idx_opt;
+        else { ICPX_TRY(icpx_reserve(ctx, ctx->scratch_idx, ctx->ns * sizeof(int))); didx = ctx->scratch_idx.as<int>(); }
+    }
+    ICPX_TRY(icp_step_enqueue(ctx, T, ctx->sums.as<double>(), didx));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sums, ctx->sums.p, ICPX_NSUMS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (idx_opt && idx_where != ICPX_DEVICE)
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(idx_opt, didx, ctx->ns * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+extern "C" int icpx_icp_step_async(icpx_ctx* ctx, const double T[16], double* sums_dev) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!sums_dev) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_step_async: sums_dev is NULL");
+    ICPX_TRY(icpx_bind(ctx));
+    return icp_step_enqueue(ctx, T, sums_dev, nullptr);
+}

@@ -1,0 +1,172 @@
+/* icpx.h — C ABI of the MI355X (gfx950) ICP / Go-ICP correspondence engine.
+ *
+ * One opaque context per GPU. Every function returns ICPX_OK (0) or a negative ICPX_E* code; the text
+ * of the last failure is available from icpx_last_error(). Nothing throws, nothing calls exit().
+ * The caller owns every buffer it passes in; the context owns its device buffers. A context is used
+ * from one host thread at a time. Calls are synchronous (they return after the work on the context's
+ * stream has completed) except those suffixed _async, which only enqueue on the context's stream and
+ * are completed by icpx_sync().
+ *
+ * Pointer arguments that carry bulk data come with a `where` argument: ICPX_HOST (pageable or pinned
+ * host memory, copied by the library) or ICPX_DEVICE (memory of the context's GPU, used in place).
+ * Small fixed-size arguments (matrices, boxes, cube lists) are always host memory unless stated.
+ *
+ * The reference (Hcque/ICP) has no FFI: these entry points replace member functions of its C++
+ * classes; each declaration cites the member it stands in for (paths relative to the reference root).
+ */
+#ifndef ICPX_H
+#define ICPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icpx_ctx icpx_ctx;
+
+enum { ICPX_HOST = 0, ICPX_DEVICE = 1 };
+
+enum {
+    ICPX_OK = 0,
+    ICPX_EINVAL = -1,   /* bad argument (null pointer, zero size, out-of-range value) */
+    ICPX_ESTATE = -2,   /* call order: a prerequisite (target / source / EDT / data) is missing */
+    ICPX_EHIP = -3,     /* a HIP runtime call failed; the text carries hipGetErrorString */
+    ICPX_ENOMEM = -4,   /* device allocation failed */
+    ICPX_ELIMIT = -5    /* a documented size limit was exceeded */
+};
+
+/* Number of doubles icpx_icp_step writes: sum p (3), sum q (3), sum p q^T (9, row-major p_r*q_c),
+ * sum |p-q|^2 (1). */
+#define ICPX_NSUMS 16
+/* Rotation-uncertainty levels of GoIcp::Init (src/GoIcp.cpp:20, MAXROTLEVEL). */
+#define ICPX_MAXROTLEVEL 20
+/* Largest EDT resolution per axis (stack entries pack indices in 10 bits). */
+#define ICPX_MAX_DIV 1023
+
+/* ---- context ------------------------------------------------------------------------------------ */
+
+int icpx_create(int device, icpx_ctx** out);
+void icpx_destroy(icpx_ctx* ctx);
+/* Text of the most recent error on this context (or of the last failed icpx_create when ctx is
+ * NULL). Never NULL. */
+const char* icpx_last_error(const icpx_ctx* ctx);
+/* Use an existing hipStream_t (passed as void*) for all work of this context; NULL restores the
+ * context's own stream. */
+int icpx_set_stream(icpx_ctx* ctx, void* hip_stream);
+int icpx_sync(icpx_ctx* ctx);
+int icpx_device(const icpx_ctx* ctx);
+
+/* ---- target cloud + nearest neighbour -------------------------------------------------------------- */
+
+/* Replaces KDTree::KDTree(cloud, 3) + KDTree::build (src/kdtree.cpp:58-89): takes the target (model)
+ * cloud, n points of 3 floats at byte stride `stride_bytes` (12 for packed xyz, 16 for the PCL
+ * point layout), and builds the uniform search grid on the GPU. Also records the float bounding box
+ * that LDT uses (src/testLDT.cpp:50). */
+int icpx_set_target(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, int where);
+
+/* Replaces the query loop of SingleThreadIcp::kdtree_search over KDTree::get_closest
+ * (src/SingleThreadIcp.cpp:194-209, src/kdtree.cpp:107-150): for each of n double-precision queries
+ * (row-major n x 3) the index of the nearest target point and the squared distance
+ * ((dx*dx + dy*dy) + dz*dz in IEEE double without fused multiply-add, src/kdtree.cpp:131-133).
+ * Ties resolve to the lowest target index. idx and d2 may each be NULL; they live where q lives. */
+int icpx_nn(icpx_ctx* ctx, const double* q_xyz, size_t n, int where, int32_t* idx, double* d2);
+
+/* Replaces KDTree::Distance (src/kdtree.cpp:91-105): float queries, widened to double; returns
+ * (float)sqrt(min squared distance). n x 3 floats in, n floats out. */
+int icpx_nn_distance(icpx_ctx* ctx, const float* q_xyz, size_t n, int where, float* dist);
+
+/* ---- ICP iteration: transform + NN + residual / cross-covariance reduction ------------------------ */
+
+/* Replaces SingleThreadIcp::setSource (src/SingleThreadIcp.cpp:66-73): the source (data) cloud that
+ * icpx_icp_step transforms. The library may keep it in a spatially sorted order internally;
+ * per-point outputs are always returned in the caller's order. */
+int icpx_set_source(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, int where);
+
+/* One pass of the hot loop of SingleThreadIcp::registration (src/SingleThreadIcp.cpp:307-316):
+ * p_i = T * [src_i; 1] in double (T = row-major 4x4, host memory, the ACCUMULATED transform
+ * finMat), q_i = nearest target point of p_i (kdtree_search, :186-214), and the sums that
+ * cal_covarance (:216-247) and the residual log of best_fit_transform (:281-287) need:
+ *   sums[0..2] = sum p, sums[3..5] = sum q, sums[6..14] = sum p q^T, sums[15] = sum |p - q|^2.
+ * The caller forms the means, H = (sum p q^T - pbar (sum q)^T) / n, and runs the 3x3 SVD on the host.
+ * sums: 16 doubles of host memory. idx_opt: NULL, or n int32 (memory kind `idx_where`) receiving the
+ * correspondences in the caller's point order. */
+int icpx_icp_step(icpx_ctx* ctx, const double T[16], double sums[ICPX_NSUMS], int32_t* idx_opt, int idx_where);
+
+/* Same, but only enqueued: sums_dev is DEVICE memory (16 doubles) valid after icpx_sync() or after
+ * any later work on the same stream — used when the sums are all-reduced across GPUs before the
+ * host reads them. */
+int icpx_icp_step_async(icpx_ctx* ctx, const double T[16], double* sums_dev);
+
+/* ---- Euclidean distance transform --------------------------------------------------------------------- */
+
+/* Replaces LDT::LDT(cloud, div, cores) (src/testLDT.cpp:40-212) for the current target: voxelisation
+ * box by the reference's rule (:50-69), splat (:74-88), and the exact squared EDT that the three
+ * passes (:91-206) compute. The parity object is the int32 squared grid before the final sqrt. */
+int icpx_edt_build(icpx_ctx* ctx, uint32_t div);
+
+/* Same with an explicit box (lower corner + cell length) instead of the reference's rule. Points whose
+ * voxel falls outside the grid are dropped. */
+int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[3], float cell_len);
+
+/* Only the kernels of icpx_edt_build, enqueued on the stream (box and buffers from the previous
+ * icpx_edt_build* call are reused): the timed region of the EDT benchmark. */
+int icpx_edt_rebuild_async(icpx_ctx* ctx);
+
+/* LDT's public fields (src/testLDT.cpp:31-35): div, _min, cellLen; plus the occupied-voxel count and
+ * the number of points dropped by the splat. Any output pointer may be NULL. */
+int icpx_edt_info(icpx_ctx* ctx, uint32_t* div, float min3[3], float* cell_len, uint64_t* occupied, uint64_t* dropped);
+
+/* Copies the squared grid out: div^3 int32 in the reference's [x][y][z] order (z fastest). */
+int icpx_edt_read(icpx_ctx* ctx, int32_t* sq_out, int where);
+
+/* Device address of the squared grid (div^3 int32, [x][y][z]); valid until the next build/destroy. */
+int icpx_edt_grid_ptr(icpx_ctx* ctx, const int32_t** sq_dev);
+
+/* Replaces LDT::Distance (src/testLDT.cpp:235-290): clamp into the box, truncate to a voxel,
+ * sqrt(sq) * cellLen + overshoot. A coordinate equal to the upper clamp indexes voxel `div` in the
+ * reference (out of range); here it is clamped to div-1. n x 3 floats in, n floats out. */
+int icpx_edt_lookup(icpx_ctx* ctx, const float* xyz, size_t n, int where, float* dist);
+
+/* ---- Go-ICP bound evaluation ---------------------------------------------------------------------------- */
+
+/* Replaces the data-side state of GoIcp::GoIcp + GoIcp::Init (src/GoIcp.cpp:82-103, :459-489): uploads
+ * the data cloud and builds maxRotDist[level][i] = (float)(2 sin(min(sqrt3 * sigma_l, pi) / 2) * |x_i|)
+ * for ICPX_MAXROTLEVEL levels with the reference's truncated constants (:17-18). Requires the EDT. */
+int icpx_goicp_set_data(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, int where);
+
+/* Copies the maxRotDist table out (ICPX_MAXROTLEVEL x n floats, host memory, caller's point order). */
+int icpx_goicp_read_maxrotdist(icpx_ctx* ctx, float* out);
+
+/* One work item of a bound-evaluation batch: the loop body of GoIcp::innerBnB for one translation
+ * child cube (src/GoIcp.cpp:384-431) under the rotation R (row-major 3x3 float, computed on the host
+ * as at :243-261). level < 0: upper-bound form (maxRotDistL == NULL); 0 <= level < ICPX_MAXROTLEVEL:
+ * lower-bound form subtracting maxRotDist[level]. */
+typedef struct icpx_bnb_item {
+    float R[9];
+    float x, y, z, w; /* child cube: lower corner and side (TransNode, src/GoIcp.cpp:35-42) */
+    int32_t level;
+} icpx_bnb_item;
+
+/* Evaluates nitems cubes in one launch. For every item: d_i = max(0, Distance(R x_i + centre) -
+ * maxRotDist[level][i]) with the float arithmetic of src/GoIcp.cpp:268-271 and :388-411, then
+ *   ub = sum d_i^2,   lb = sum max(0, d_i - (float)(sqrt3/2 * w))^2.
+ * ub, lb: nitems doubles each (host), accumulated on the device in double (tree order).
+ * mindis_opt: NULL, or nitems x n floats (host) receiving every d_i in the caller's point order, from
+ * which the reference's sequential float sums (:416-431) can be reproduced bit for bit. */
+int icpx_bnb_eval(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* ub, double* lb, float* mindis_opt);
+
+/* Enqueue-only variant for multi-GPU use: out_dev is DEVICE memory, 2 * nitems doubles laid out
+ * [ub_0 .. ub_{n-1}, lb_0 .. lb_{n-1}]. items is host memory and is copied before the call returns. */
+int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev);
+
+/* Replaces the SSE loop of GoIcp::runICP (src/GoIcp.cpp:113-135) and the initial error of OuterBnB
+ * (:161-172): d_i = Distance((float)(T * [x_i;1])) for the data cloud, T row-major 4x4 double (host);
+ * writes every d_i (n floats, host, caller's order) so the caller can form the sequential float sum. */
+int icpx_goicp_residuals(icpx_ctx* ctx, const double T[16], float* dist_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICPX_H */

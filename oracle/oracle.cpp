@@ -550,8 +550,10 @@ void orc_goicp_maxrotdist(const float* data, int64_t n, float* out) {
         double tmp = sigma * ORC_SQRT3;
         if (tmp > ORC_PI) tmp = ORC_PI;
         for (int64_t j = 0; j < n; j++) {
-            double x = data[3 * j], y = data[3 * j + 1], z = data[3 * j + 2];
-            double nrm = std::sqrt(x * x + y * y + z * z);
+            // SQ() of a float member is a float product and std::sqrt picks the float overload
+            // (src/GoIcp.cpp:464-466); the result is then widened into the double table.
+            float x = data[3 * j], y = data[3 * j + 1], z = data[3 * j + 2];
+            double nrm = (double)std::sqrt(x * x + y * y + z * z);
             out[(size_t)l * n + j] = (float)(2 * std::sin(tmp / 2) * nrm);
         }
     }

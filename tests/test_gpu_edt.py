@@ -1,0 +1,75 @@
+"""GPU parity: exact squared EDT + lookup through the C ABI against the CPU oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _build_and_check(ctx, O, pts, div, caps=None):
+    ctx.set_target(pts)
+    ctx.edt_build(div)
+    info = ctx.edt_info()
+    mn, cell = O.ldt_box(pts, div)
+    assert np.array_equal(info["min"], mn) and info["cell"] == cell      # box rule, bit for bit
+    occ, dropped = O.ldt_splat(pts, div, mn, cell)
+    assert info["occupied"] == int(occ.sum()) and info["dropped"] == dropped
+    sq = ctx.edt_read()
+    ref = O.edt_meijster(occ)
+    assert np.array_equal(sq, ref), f"{(sq != ref).sum()} voxels differ at div={div}"
+    return sq, mn, cell
+
+
+@pytest.mark.parametrize("div", [32, 64, 100])
+def test_edt_bunny_small(gpu_ctx, oracle, bunny045, div):
+    _build_and_check(gpu_ctx, oracle, bunny045, div)
+
+
+def test_edt_bunny_300_and_lookup(gpu_ctx, oracle, bunny045, bunny000):
+    sq, mn, cell = _build_and_check(gpu_ctx, oracle, bunny045, 300)
+    assert cell == np.float32(0.0011251526)
+    # lookup: in-box queries (bunny000) and queries far outside the box
+    rng = np.random.default_rng(3)
+    far = (rng.uniform(-1, 1, (5000, 3))).astype(np.float32)
+    q = np.ascontiguousarray(np.concatenate([bunny000, far]))
+    got = gpu_ctx.edt_lookup(q)
+    want = oracle.ldt_lookup(sq, mn, cell, q)
+    assert np.array_equal(got, want)
+
+
+def test_edt_dense_random_and_spill(gpu_ctx, oracle):
+    """Dense random occupancy drives envelope stacks deep; a tiny LDS capacity forces the spill tier."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    div = 96
+    pts = rng.uniform(0.0, 1.0, (200000, 3)).astype(np.float32)
+    mn = np.zeros(3, np.float32); cell = np.float32(1.0 / div)
+    gpu_ctx.set_target(pts)
+    gpu_ctx.edt_build(div, box=(mn, cell))
+    occ, dropped = oracle.ldt_splat(pts, div, mn, cell)
+    ref = oracle.edt_meijster(occ)
+    assert np.array_equal(gpu_ctx.edt_read(), ref)
+    assert gpu_ctx.edt_info()["dropped"] == dropped
+
+
+def test_edt_single_voxel_and_brute(gpu_ctx, oracle):
+    pts = np.array([[0.31, 0.52, 0.77]], np.float32)
+    mn = np.zeros(3, np.float32); cell = np.float32(1.0 / 40)
+    gpu_ctx.set_target(pts)
+    gpu_ctx.edt_build(40, box=(mn, cell))
+    occ, _ = oracle.ldt_splat(pts, 40, mn, cell)
+    assert occ.sum() == 1
+    assert np.array_equal(gpu_ctx.edt_read(), oracle.edt_brute(occ))
+
+
+def test_edt_errors(gpu_ctx):
+    from icp_amd import IcpxError
+    from icp_amd.api import Context
+    fresh = Context(0)
+    with pytest.raises(IcpxError):
+        fresh.edt_build(64)            # no target yet
+    fresh.set_target(np.zeros((4, 3), np.float32) + np.arange(4, dtype=np.float32)[:, None])
+    with pytest.raises(IcpxError):
+        fresh.edt_build(5000)          # above ICPX_MAX_DIV
+    with pytest.raises(IcpxError):
+        fresh.edt_lookup(np.zeros((1, 3), np.float32))   # nothing built
+    fresh.close()

@@ -1,0 +1,26 @@
+"""GPU parity: fused transform + NN + covariance sums through the C ABI against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import rigid
+
+pytestmark = pytest.mark.gpu
+
+
+def _sums_ref(O, src, tgt, T):
+    p = src.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    idx, d2 = O.nn_brute(np.ascontiguousarray(p), tgt)
+    q = tgt[idx].astype(np.float64)
+    s = np.empty(16)
+    s[0:3] = p.sum(0); s[3:6] = q.sum(0); s[6:15] = (p.T @ q).reshape(9); s[15] = d2.sum()
+    return s, idx
+
+
+def test_icp_step_sums_and_idx(gpu_ctx, oracle, bunny000, bunny045):
+    gpu_ctx.set_target(bunny045)
+    gpu_ctx.set_source(bunny000)
+    for T in (np.eye(4), rigid([0.2, -1, 0.4], 8.0, [0.003, 0.001, -0.002])):
+        sums, idx = gpu_ctx.icp_step(T, want_idx=True)
+        ref, ridx = _sums_ref(oracle, bunny000, bunny045, T)
+        assert np.array_equal(idx, ridx)
+        np.testing.assert_allclose(sums, ref, rtol=1e-12, atol=1e-12)

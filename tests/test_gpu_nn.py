@@ -1,0 +1,98 @@
+"""GPU parity: grid NN through the C ABI against brute force (bit-exact indices and squared distances)."""
+import numpy as np
+import pytest
+
+from conftest import synth_surface, rigid
+
+pytestmark = pytest.mark.gpu
+
+
+def test_nn_bunny_identity(gpu_ctx, oracle, bunny000, bunny045):
+    gpu_ctx.set_target(bunny045)
+    q = bunny000.astype(np.float64)
+    idx, d2 = gpu_ctx.nn(q)
+    ridx, rd2 = oracle.nn_brute(q, bunny045)
+    assert np.array_equal(d2, rd2)
+    assert np.array_equal(idx, ridx)          # includes the 52 exact-tie queries (lowest index wins)
+    # the reference's kd-tree returns the same distances (its tie order differs in 25 queries)
+    kidx, kd2 = oracle.KdTree(bunny045).nn(q)
+    assert np.array_equal(d2, kd2) and (kidx != idx).sum() == 25
+
+
+def test_nn_double_queries_after_transform(gpu_ctx, oracle, bunny000, bunny045):
+    T = rigid([0.3, 1.0, -0.2], 17.0, [0.01, -0.02, 0.005])
+    q = np.ascontiguousarray(bunny000.astype(np.float64) @ T[:3, :3].T + T[:3, 3])
+    gpu_ctx.set_target(bunny045)
+    idx, d2 = gpu_ctx.nn(q)
+    ridx, rd2 = oracle.nn_brute(q, bunny045)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+def test_nn_far_and_outside_queries(gpu_ctx, oracle, bunny045):
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-0.6, 0.6, (3000, 3))
+    q[:10] *= 50.0                                   # very far away
+    gpu_ctx.set_target(bunny045)
+    idx, d2 = gpu_ctx.nn(np.ascontiguousarray(q))
+    ridx, rd2 = oracle.nn_brute(q, bunny045)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+def test_nn_duplicates_and_degenerate_targets(gpu_ctx, oracle):
+    rng = np.random.default_rng(9)
+    base = rng.uniform(-1, 1, (500, 3)).astype(np.float32)
+    tgt = np.ascontiguousarray(np.concatenate([base, base[::-1], base[:100]]))   # exact duplicates
+    q = np.ascontiguousarray(np.concatenate([base.astype(np.float64), rng.uniform(-1, 1, (700, 3))]))
+    gpu_ctx.set_target(tgt)
+    idx, d2 = gpu_ctx.nn(q)
+    ridx, rd2 = oracle.nn_brute(q, tgt)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    # all points in a plane / on a line / a single point
+    for tgt in (np.c_[base[:, :2], np.zeros(500, np.float32)], np.c_[base[:, :1], np.zeros((500, 2), np.float32)],
+                np.array([[0.25, -0.5, 0.125]], np.float32)):
+        tgt = np.ascontiguousarray(tgt, np.float32)
+        gpu_ctx.set_target(tgt)
+        idx, d2 = gpu_ctx.nn(q)
+        ridx, rd2 = oracle.nn_brute(q, tgt)
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+def test_nn_synthetic_200k(gpu_ctx, oracle):
+    tgt = synth_surface(200_000, 42)
+    T = rigid([1, 1, 1], 10.0, [0.02, -0.01, 0.015])
+    src = synth_surface(20_000, 43, noise=1e-3).astype(np.float64)
+    q = np.ascontiguousarray(src @ T[:3, :3].T + T[:3, 3])
+    gpu_ctx.set_target(tgt)
+    idx, d2 = gpu_ctx.nn(q)
+    ridx, rd2 = oracle.nn_brute(q, tgt)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+def test_nn_distance_matches_kdtree_distance(gpu_ctx, oracle, bunny000, bunny045):
+    gpu_ctx.set_target(bunny045)
+    got = gpu_ctx.nn_distance(bunny000)
+    want = oracle.KdTree(bunny045).distance(bunny000)
+    assert np.array_equal(got, want)
+
+
+def test_nn_device_pointers(gpu_ctx, oracle, bunny000, bunny045):
+    import torch
+    gpu_ctx.set_target(torch.from_numpy(bunny045).cuda())
+    q = torch.from_numpy(bunny000.astype(np.float64)).cuda()
+    idx, d2 = gpu_ctx.nn(q)
+    ridx, rd2 = oracle.nn_brute(bunny000.astype(np.float64), bunny045)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d2.cpu().numpy(), rd2)
+
+
+def test_nn_empty_and_errors(gpu_ctx, bunny045):
+    from icp_amd import IcpxError
+    from icp_amd.api import Context
+    fresh = Context(0)
+    with pytest.raises(IcpxError):
+        fresh.nn(np.zeros((3, 3)))
+    with pytest.raises(IcpxError):
+        fresh.set_target(np.zeros((0, 3), np.float32))
+    fresh.close()
+    gpu_ctx.set_target(bunny045)
+    idx, d2 = gpu_ctx.nn(np.zeros((0, 3)))
+    assert idx.shape == (0,)
