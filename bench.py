@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the ICP / Go-ICP correspondence hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Headline workload (N = 1): the exact squared Euclidean distance transform of the bunny045 scan on a
+300^3 grid (27 M voxels), voxelised by the reference's box rule; one step = one full build (clear,
+splat, census, z+y pass, x pass) with the target cloud already resident in HBM. `value` is voxels/s.
+For N > 1 the path does not shard (every pass needs whole rows along its axis): every rank builds its
+own replica and `value` is the aggregate over ranks (weak scaling, no data-path collective).
+
+The same JSON line carries
+  roofline      the dominant EDT kernel (pass x) priced against the 8 TB/s HBM peak from its
+                algorithmic bytes (8 B per voxel: one int32 read + one int32 write), timed with HIP
+                events inside the timed region;
+  cpu_baseline  the CPU restatement of the reference's three-pass EDT (oracle/, OpenMP) on this box's
+                host cores, on a bounded number of repetitions of the same 300^3 build;
+  extra         NN / ICP-iteration throughput of the synthetic 1 M x 1 M cloud pair (query-sharded over
+                the ranks, one 16-double all-reduce per iteration) and DT-lookup throughput.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (spec)
+DIV = 300
+
+
+def load_scan(name):
+    return np.fromfile(os.path.join(ROOT, "tests", "golden", name + ".xyz.f32"), dtype="<f4").reshape(-1, 3).astype(np.float32)
+
+
+def synth_surface(n, seed, noise=0.0):
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(-1.0, 1.0, n)
+    phi = rng.uniform(0.0, 2 * np.pi, n)
+    theta = np.arccos(u)
+    r = 0.35 * (1 + 0.15 * np.sin(3 * theta) * np.cos(5 * phi))
+    p = np.stack([r * np.sin(theta) * np.cos(phi), r * np.sin(theta) * np.sin(phi), r * np.cos(theta)], 1)
+    if noise:
+        p = p + rng.normal(0.0, noise, p.shape)
+    return p.astype(np.float32)
+
+
+def rigid(axis, deg, t):
+    a = np.asarray(axis, float); a /= np.linalg.norm(a)
+    th = np.deg2rad(deg)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    return T
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-extra", action="store_true", help="skip the NN / ICP / lookup extras")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--nn-points", type=int, default=1_000_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from icp_amd.api import Context
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    ctx = Context(local)
+    tgt = load_scan("bunny045")
+    tgt_dev = torch.from_numpy(tgt).to(dev)
+    ctx.set_target(tgt_dev)            # target resident in HBM before anything is timed
+    ctx.edt_build(DIV)
+    info = ctx.edt_info()
+    voxels = DIV ** 3
+
+    # ---- headline: EDT build ------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        ctx.edt_rebuild_async()
+    ctx.sync()
+    barrier()
+    t0 = time.perf_counter()
+    stage_ms = ctx.edt_rebuild_timed(args.steps)     # K back-to-back builds, HIP events between the stages
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    value = world * voxels * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    stage_names = ["clear", "splat", "census", "pass_zy", "pass_x"]
+    per_stage = {k: float(v) / args.steps for k, v in zip(stage_names, stage_ms)}
+    dom = "pass_x"
+    alg_bytes = 8.0 * voxels                       # one int32 read + one int32 write per voxel
+    achieved = alg_bytes / (per_stage[dom] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_edt_pass_x", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_stage[dom],
+                "whole_build": {"algorithmic_bytes": 24.0 * voxels, "GB/s": 24.0 * voxels / (sum(per_stage.values()) * 1e-3) / 1e9,
+                                "frac": 24.0 * voxels / (sum(per_stage.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "stage_ms": per_stage}
+
+    extra = {}
+    if not args.no_extra:
+        # DT lookup: bunny000 points against the grid
+        q = torch.from_numpy(load_scan("bunny000")).to(dev)
+        qrep = q.repeat(25, 1).contiguous()       # ~1 M queries
+        ctx.edt_lookup(qrep)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.edt_lookup(qrep)
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t0)
+        extra["dt_lookup_queries_per_s"] = world * qrep.shape[0] * 20 / el
+
+        # synthetic 1 M x 1 M ICP, query-sharded
+        n = args.nn_points
+        tgt_s = synth_surface(n, 42)
+        src_all = synth_surface(n, 43, noise=1e-3).astype(np.float64)
+        Tm = rigid([1, 1, 1], 10.0, [0.02, -0.01, 0.015])
+        src_all = (src_all @ Tm[:3, :3].T + Tm[:3, 3]).astype(np.float32)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        ctx2 = Context(local)
+        ctx2.set_target(torch.from_numpy(tgt_s).to(dev))
+        ctx2.set_source(torch.from_numpy(np.ascontiguousarray(src_all[lo:hi])).to(dev))
+        sums = torch.zeros(16, dtype=torch.float64, device=dev)
+        ctx2.set_stream(torch.cuda.current_stream().cuda_stream)
+        T = np.eye(4)
+        iters = 30
+
+        def icp_iter(T):
+            ctx2.icp_step_async(T, sums)
+            if world > 1:
+                dist.all_reduce(sums)
+            s = sums.cpu().numpy()
+            from icp_amd.host import kabsch_from_sums
+            return kabsch_from_sums(s, n) @ T
+
+        icp_iter(T)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(iters):
+            T = icp_iter(T)
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t0)
+        extra["icp_1m_iterations_per_s"] = iters / el
+        extra["nn_queries_per_s"] = n * iters / el
+        extra["icp_1m_rot_err_deg"] = float(np.rad2deg(np.arccos(np.clip((np.trace(T[:3, :3] @ Tm[:3, :3]) - 1) / 2, -1, 1))))
+        extra["nn_roofline_frac"] = (36.0 * n + 12.0 * n * world) * iters / el / 1e9 / (HBM_PEAK_GBS * world)
+        ctx2.close()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import oracle as O
+        mn, cell = O.ldt_box(tgt, DIV)
+        occ, _ = O.ldt_splat(tgt, DIV, mn, cell)
+        threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+        O.edt_meijster(occ, threads=threads)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0 and reps < 40:
+            O.edt_meijster(occ, threads=threads); reps += 1
+        el = time.perf_counter() - t0
+        cpu = {"value": voxels * reps / el, "unit": "voxels/s", "cores": threads, "kind": "port",
+               "sample": f"{reps} builds of the same 300^3 bunny045 grid (three-pass EDT restatement, OpenMP)"}
+
+    if rank == 0:
+        line = {"metric": "EDT voxels/s", "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "int32", "data": "bunny045 scan (40097 points) voxelised on a 300^3 grid",
+                "config": {"workload": "EDT 300^3 from bunny045 (reference box rule), full build per step",
+                           "div": DIV, "occupied_voxels": int(info["occupied"]), "parallelism": "replicas only" if world > 1 else "1 GPU"},
+                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,12 @@ class Context:
     def edt_rebuild_async(self):
         self._ck(self._lib.icpx_edt_rebuild_async(self._h))
 
+    def edt_rebuild_timed(self, reps):
+        """Summed per-stage milliseconds over `reps` rebuilds: clear, splat, census, pass zy, pass x."""
+        ms = (C.c_float * 5)()
+        self._ck(self._lib.icpx_edt_rebuild_timed(self._h, reps, ms))
+        return np.array(list(ms), np.float64)
+
     def edt_info(self):
         div = C.c_uint32(); mn = (C.c_float * 3)(); cell = C.c_float(); occ = C.c_uint64(); dr = C.c_uint64()
         self._ck(self._lib.icpx_edt_info(self._h, C.byref(div), mn, C.byref(cell), C.byref(occ), C.byref(dr)))

@@ -1,0 +1,784 @@
+// Host side of the registration classes (see icpx_host.hpp). Everything per-point runs on the GPU
+// through include/icpx.h; what stays here is what the reference also does serially on the host:
+// 3x3 SVD, 4x4 algebra, priority queues and the branch-and-bound decisions.
+#include "icpx_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <queue>
+
+namespace icp {
+
+#define PI 3.1415926536        // src/GoIcp.cpp:17 (truncated literal kept on purpose)
+#define SQRT3 1.732050808      // src/GoIcp.cpp:18
+#define MAXROTLEVEL ICPX_MAXROTLEVEL
+
+// ---- small algebra ------------------------------------------------------------------------------------
+
+Matrix4d Matrix4d::operator*(const Matrix4d& o) const {
+    Matrix4d r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double a = 0;
+            for (int k = 0; k < 4; k++) a += m[4 * i + k] * o.m[4 * k + j];
+            r.m[4 * i + j] = a;
+        }
+    return r;
+}
+
+static double det3(const Matrix3d& M) {
+    return M(0, 0) * (M(1, 1) * M(2, 2) - M(1, 2) * M(2, 1)) - M(0, 1) * (M(1, 0) * M(2, 2) - M(1, 2) * M(2, 0)) +
+           M(0, 2) * (M(1, 0) * M(2, 1) - M(1, 1) * M(2, 0));
+}
+
+// One-sided (Hestenes) Jacobi SVD of a 3x3 matrix: columns of W = A V are rotated pairwise until they
+// are orthogonal; singular values are their norms. Accurate to working precision without forming A^T A.
+void svd3(const Matrix3d& A, Matrix3d& U, double sig[3], Matrix3d& V) {
+    double W[3][3], Vv[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { W[i][j] = A(i, j); Vv[i][j] = (i == j); }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 3; i++) { alpha += W[i][p] * W[i][p]; beta += W[i][q] * W[i][q]; gamma += W[i][p] * W[i][q]; }
+                if (gamma == 0.0) continue;
+                off = std::max(off, std::fabs(gamma) / std::sqrt(std::max(alpha * beta, 1e-300)));
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < 3; i++) {
+                    const double wp = W[i][p], wq = W[i][q];
+                    W[i][p] = c * wp - s * wq; W[i][q] = s * wp + c * wq;
+                    const double vp = Vv[i][p], vq = Vv[i][q];
+                    Vv[i][p] = c * vp - s * vq; Vv[i][q] = s * vp + c * vq;
+                }
+            }
+        if (off < 1e-16) break;
+    }
+    double nrm[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; j++) nrm[j] = std::sqrt(W[0][j] * W[0][j] + W[1][j] * W[1][j] + W[2][j] * W[2][j]);
+    std::sort(ord, ord + 3, [&](int a, int b) { return nrm[a] > nrm[b]; });
+    double u[3][3];
+    for (int j = 0; j < 3; j++) {
+        const int o = ord[j];
+        sig[j] = nrm[o];
+        for (int i = 0; i < 3; i++) { V(i, j) = Vv[i][o]; u[j][i] = W[i][o]; }
+    }
+    // Normalise U; complete it when the input is rank deficient.
+    const double tiny = 1e-14 * std::max(sig[0], 1e-300);
+    if (sig[0] > 0) for (int i = 0; i < 3; i++) u[0][i] /= sig[0]; else { u[0][0] = 1; u[0][1] = u[0][2] = 0; }
+    if (sig[1] > tiny) for (int i = 0; i < 3; i++) u[1][i] /= sig[1];
+    else {
+        int mI = 0;
+        for (int i = 1; i < 3; i++) if (std::fabs(u[0][i]) < std::fabs(u[0][mI])) mI = i;
+        double e[3] = {0, 0, 0}; e[mI] = 1;
+        const double d = u[0][mI];
+        double n = 0;
+        for (int i = 0; i < 3; i++) { u[1][i] = e[i] - d * u[0][i]; n += u[1][i] * u[1][i]; }
+        n = std::sqrt(n);
+        for (int i = 0; i < 3; i++) u[1][i] /= n;
+    }
+    const double cx[3] = {u[0][1] * u[1][2] - u[0][2] * u[1][1], u[0][2] * u[1][0] - u[0][0] * u[1][2], u[0][0] * u[1][1] - u[0][1] * u[1][0]};
+    if (sig[2] > tiny) {
+        const double d = cx[0] * u[2][0] + cx[1] * u[2][1] + cx[2] * u[2][2];
+        for (int i = 0; i < 3; i++) u[2][i] = (d < 0 ? -cx[i] : cx[i]);
+    } else for (int i = 0; i < 3; i++) u[2][i] = cx[i];
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) U(i, j) = u[j][i];
+}
+
+// R = (U V^T)^T; when det R < 0 the last row of V^T is negated first (src/SingleThreadIcp.cpp:256-266).
+Matrix3d kabsch_rotation(const Matrix3d& H) {
+    Matrix3d U, V, R;
+    double s[3];
+    svd3(H, U, s, V);
+    auto make = [&](double sgn) {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) R(i, j) = U(j, 0) * V(i, 0) + U(j, 1) * V(i, 1) + sgn * U(j, 2) * V(i, 2);
+    };
+    make(1.0);
+    if (det3(R) < 0) make(-1.0);
+    return R;
+}
+
+// Row r of M * [p;1], multiply then add from a zero accumulator in k order — the order of the 4x4 by
+// 4xN products at src/SingleThreadIcp.cpp:277, :302, :320.
+static inline void apply4(const Matrix4d& M, const double p[3], double out[3]) {
+    for (int r = 0; r < 3; r++) {
+        double a = 0.0;
+        a += M.m[4 * r + 0] * p[0];
+        a += M.m[4 * r + 1] * p[1];
+        a += M.m[4 * r + 2] * p[2];
+        a += M.m[4 * r + 3] * 1.0;
+        out[r] = a;
+    }
+}
+
+// ---- Device ---------------------------------------------------------------------------------------------
+
+Device::Device(int device) {
+    int rc = icpx_create(device, &ctx_);
+    if (rc != ICPX_OK) throw IcpxFailure(rc, icpx_last_error(nullptr));
+}
+Device::~Device() { icpx_destroy(ctx_); }
+void Device::check(int rc) const {
+    if (rc != ICPX_OK) throw IcpxFailure(rc, icpx_last_error(ctx_));
+}
+
+static void ensure_target_on(const DevicePtr& dev, const PointCloudTPtr& cloud) {
+    if (!cloud || cloud->points.empty()) throw IcpxFailure(ICPX_EINVAL, "empty target cloud");
+    if (dev->target_tag == cloud.get()) return;
+    dev->check(icpx_set_target(dev->ctx(), &cloud->points[0].x, cloud->points.size(), sizeof(Point3f), ICPX_HOST));
+    dev->target_tag = cloud.get();
+    dev->edt_div = 0;
+}
+
+static void ensure_edt_on(const DevicePtr& dev, const PointCloudTPtr& cloud, uint32_t div) {
+    ensure_target_on(dev, cloud);
+    if (dev->edt_div == div) return;
+    dev->check(icpx_edt_build(dev->ctx(), div));
+    dev->edt_div = div;
+}
+
+// ---- KDTree ---------------------------------------------------------------------------------------------
+
+KDTree::KDTree(const PointCloudTPtr& cloudptr, int _dims, DevicePtr d) : dims(_dims), target(cloudptr), dev(d ? d : std::make_shared<Device>(0)) {
+    if (_dims != 3) throw IcpxFailure(ICPX_EINVAL, "KDTree: only 3 dimensions are supported");
+    ensure_target_on(dev, target);
+}
+
+void KDTree::get_closest(const double* q, size_t n, int32_t* idx, double* d2) {
+    ensure_target_on(dev, target);
+    dev->check(icpx_nn(dev->ctx(), q, n, ICPX_HOST, idx, d2));
+}
+
+int KDTree::get_closest(const Vector3d& x) {
+    int32_t idx = -1;
+    get_closest(x.v, 1, &idx, nullptr);
+    return idx;
+}
+
+void KDTree::Distance(const float* q, size_t n, float* out) {
+    ensure_target_on(dev, target);
+    dev->check(icpx_nn_distance(dev->ctx(), q, n, ICPX_HOST, out));
+}
+
+float KDTree::Distance(float x0, float x1, float x2) {
+    const float q[3] = {x0, x1, x2};
+    float out = 0;
+    Distance(q, 1, &out);
+    return out;
+}
+
+// ---- LDT --------------------------------------------------------------------------------------------------
+
+LDT::LDT(const PointCloudTPtr& cloud, uint32_t _div, int _core, DevicePtr d) : div(_div), CORES(_core), dev(d ? d : std::make_shared<Device>(0)) {
+    ensure_edt_on(dev, cloud, div);
+    float mn[3];
+    dev->check(icpx_edt_info(dev->ctx(), nullptr, mn, &cellLen, &occupied, nullptr));
+    _min = Point3f(mn[0], mn[1], mn[2]);
+    _max = Point3f(mn[0] + cellLen * div, mn[1] + cellLen * div, mn[2] + cellLen * div);
+}
+
+void LDT::Distance(const float* q, size_t n, float* out) { dev->check(icpx_edt_lookup(dev->ctx(), q, n, ICPX_HOST, out)); }
+
+float LDT::Distance(float x, float y, float z) {
+    const float q[3] = {x, y, z};
+    float out = 0;
+    Distance(q, 1, &out);
+    return out;
+}
+
+const std::vector<int32_t>& LDT::squared() {
+    if (sq_.empty()) {
+        sq_.resize((size_t)div * div * div);
+        dev->check(icpx_edt_read(dev->ctx(), sq_.data(), ICPX_HOST));
+    }
+    return sq_;
+}
+
+const std::vector<float>& LDT::grid() {
+    if (g_.empty()) {
+        const std::vector<int32_t>& s = squared();
+        g_.resize(s.size());
+        for (size_t i = 0; i < s.size(); i++) g_[i] = std::sqrt((float)s[i]);   // src/testLDT.cpp:200
+    }
+    return g_;
+}
+
+// ---- SingleThreadIcp -----------------------------------------------------------------------------------------
+
+SingleThreadIcp::SingleThreadIcp(PointCloudTPtr _s, PointCloudTPtr _t, int _iter, DevicePtr d)
+    : source(_s), target(_t), max_iter(_iter), dev(d ? d : std::make_shared<Device>(0)) {
+    Nm = (int)target->points.size();
+    setTarget(target);
+    setSource(source);
+}
+
+void SingleThreadIcp::ensure_target() { ensure_target_on(dev, target); }
+
+void SingleThreadIcp::setTarget(PointCloudTPtr _target) {
+    target = _target;
+    Nm = (int)target->points.size();
+    ensure_target();
+    // cal_mean(tar, mean_tar): sequential double sum of the widened floats (src/common.hpp:65-71)
+    double s[3] = {0, 0, 0};
+    for (const Point3f& p : target->points) { s[0] += (double)p.x; s[1] += (double)p.y; s[2] += (double)p.z; }
+    for (int c = 0; c < 3; c++) mean_tar[c] = s[c] / (double)Nm;
+}
+
+void SingleThreadIcp::setSource(const PointCloudTPtr _source) {
+    source = _source;
+    Nd = (int)source->points.size();
+    if (Nd == 0) throw IcpxFailure(ICPX_EINVAL, "empty source cloud");
+    dev->check(icpx_set_source(dev->ctx(), &source->points[0].x, (size_t)Nd, sizeof(Point3f), ICPX_HOST));
+    Nd_global = Nd;
+    if (comm.world > 1 && comm.allreduce_sum_host) {
+        double n = (double)Nd;
+        comm.allreduce_sum_host(&n, 1, comm.user);
+        Nd_global = (long long)n;
+    }
+    if (keep_correspondences) Neighbour.pointsPARA.resize(Nd);
+}
+
+void SingleThreadIcp::kdtree_search() {
+    ensure_target();
+    if (comm.world > 1) {
+        if (!comm.allreduce_sum_host) throw IcpxFailure(ICPX_EINVAL, "Collective without allreduce_sum_host");
+        dev->check(icpx_icp_step(dev->ctx(), finMat.m, sums_, keep_correspondences ? Neighbour.pointsPARA.data() : nullptr, ICPX_HOST));
+        comm.allreduce_sum_host(sums_, ICPX_NSUMS, comm.user);
+    } else {
+        if (keep_correspondences) Neighbour.pointsPARA.resize(Nd);
+        dev->check(icpx_icp_step(dev->ctx(), finMat.m, sums_, keep_correspondences ? Neighbour.pointsPARA.data() : nullptr, ICPX_HOST));
+    }
+}
+
+void SingleThreadIcp::cal_covarance() {
+    const double N = (double)Nd_global;
+    for (int c = 0; c < 3; c++) mean_tmpdata[c] = sums_[c] / N;
+    // The reference adds the matched target points onto the PREVIOUS mean before dividing
+    // (src/SingleThreadIcp.cpp:229-231); reproduced, because it moves the result by ~1e-4.
+    for (int c = 0; c < 3; c++) mean_tar[c] = (mean_tar[c] + sums_[3 + c]) / N;
+    // sum (p - pbar)(q - m)^T = sum p q^T - pbar (sum q)^T for any m, since sum (p - pbar) = 0.
+    const double denom = (double)(float)Nd_global;   // "/= (float)Nd", :244
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) Neighbour.covariance(r, c) = (sums_[6 + 3 * r + c] - mean_tmpdata[r] * sums_[3 + c]) / denom;
+    mse_trace.push_back(sums_[15] / N);
+}
+
+Matrix4d& SingleThreadIcp::best_fit_transform() {
+    const Matrix3d R = kabsch_rotation(Neighbour.covariance);
+    T = Matrix4d::Identity();
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T(r, c) = R(r, c);
+        T(r, 3) = mean_tar[r] - (R(r, 0) * mean_tmpdata[0] + R(r, 1) * mean_tmpdata[1] + R(r, 2) * mean_tmpdata[2]);
+    }
+    T_trace.push_back(T);
+    return T;
+}
+
+ICP_res SingleThreadIcp::registration(Matrix4d& guess, const PointCloudTPtr& pData) {
+    if (pData.get() != source.get() || Nd != (int)pData->points.size()) setSource(pData);
+    finMat = guess;
+    mse_trace.clear();
+    T_trace.clear();
+    for (int iter = 0; iter < max_iter; iter++) {
+        kdtree_search();
+        cal_covarance();
+        const Matrix4d curMat = best_fit_transform();
+        finMat = curMat * finMat;
+    }
+    ICP_res ans;
+    ans.resN3.data.resize((size_t)Nd * 3);
+    for (int i = 0; i < Nd; i++) {
+        const Point3f& s = source->points[i];
+        const double p[3] = {(double)s.x, (double)s.y, (double)s.z};
+        apply4(finMat, p, &ans.resN3.data[3 * (size_t)i]);
+    }
+    ans.transMat = finMat;
+    return ans;
+}
+
+// ---- GoIcp ----------------------------------------------------------------------------------------------------
+
+GoIcp::GoIcp(PointCloudTPtr pModel_, PointCloudTPtr pData_, int _iter, double _mse, DevicePtr d, uint32_t dt_div)
+    : pModel(pModel_), pData(pData_), mseThresh((float)_mse), icp(pData_, pModel_, 10, d ? d : std::make_shared<Device>(0)), ITER(_iter) {
+    dev = icp.dev;
+    InitRot.a = InitRot.b = InitRot.c = (float)-PI;
+    InitRot.w = (float)(2 * PI);
+    InitRot.l = 0;
+    InitRot.lb = 0; InitRot.ub = 0;
+    InitTrans.lb = 0; InitTrans.ub = 0;
+    InitTrans.x = -0.5; InitTrans.y = -0.5; InitTrans.z = -0.5;
+    InitTrans.w = 1.0;
+    Nd = (int)pData->points.size();
+    Nm = (int)pModel->points.size();
+    minDis.resize(Nd);
+    ensure_edt_on(dev, pModel, dt_div);
+    dev->check(icpx_goicp_set_data(dev->ctx(), &pData->points[0].x, (size_t)Nd, sizeof(Point3f), ICPX_HOST));
+    optError = 0; sseThresh = 0;
+    optNodeRot = InitRot; optNodeTrans = InitTrans;
+    for (int i = 0; i < 9; i++) R_[i] = (i % 4 == 0);
+}
+
+GoIcp::~GoIcp() { clear(); }
+
+void GoIcp::Init() {
+    clear();
+    std::vector<float> table((size_t)MAXROTLEVEL * Nd);
+    dev->check(icpx_goicp_read_maxrotdist(dev->ctx(), table.data()));
+    maxRotDist = new float*[MAXROTLEVEL];
+    for (int l = 0; l < MAXROTLEVEL; l++) {
+        maxRotDist[l] = new float[Nd];
+        std::memcpy(maxRotDist[l], table.data() + (size_t)l * Nd, sizeof(float) * Nd);
+    }
+    optNodeRot = InitRot;
+    optNodeTrans = InitTrans;
+    optMat = Matrix4d::Identity();
+    sseThresh = Nd * mseThresh;
+}
+
+void GoIcp::clear() {
+    if (!maxRotDist) return;
+    for (int i = 0; i < MAXROTLEVEL; i++) delete[] maxRotDist[i];
+    delete[] maxRotDist;
+    maxRotDist = nullptr;
+}
+
+float GoIcp::runICP(Matrix4d& tmpMat) {
+    ICP_res r = icp.registration(tmpMat, pData);
+    tmpMat = r.transMat;
+    std::vector<float> dist(Nd);
+    dev->check(icpx_goicp_residuals(dev->ctx(), tmpMat.m, dist.data()));
+    float SSE = 0.0f;
+    for (int i = 0; i < Nd; i++) SSE += dist[i] * dist[i];   // error[i] = dis*dis, then a float sum (:127, :133-135)
+    return SSE;
+}
+
+int GoIcp::cur_level_of(const float* maxDistL) const {
+    if (!maxDistL) return -1;
+    if (maxRotDist)
+        for (int l = 0; l < MAXROTLEVEL; l++) if (maxRotDist[l] == maxDistL) return l;
+    throw IcpxFailure(ICPX_EINVAL, "innerBnB: maxDistL must be NULL or one of maxRotDist[level]");
+}
+
+// Evaluates a batch of cubes; with several ranks each one evaluates a contiguous slice and the slices
+// are combined by a sum all-reduce (every rank then holds every bound and takes identical decisions).
+void GoIcp::eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub, std::vector<float>& lb) {
+    const size_t n = items.size();
+    ub.assign(n, 0.f); lb.assign(n, 0.f);
+    if (n == 0) return;
+    inner_evals += (long long)n;
+    launches++;
+    size_t lo = 0, hi = n;
+    if (comm.world > 1) { lo = n * comm.rank / comm.world; hi = n * (comm.rank + 1) / comm.world; }
+    std::vector<double> both(2 * n, 0.0);
+    if (hi > lo) {
+        const size_t m = hi - lo;
+        if (parity_sums) {
+            std::vector<double> u(m), l(m);
+            std::vector<float> md(m * (size_t)Nd);
+            dev->check(icpx_bnb_eval(dev->ctx(), items.data() + lo, m, u.data(), l.data(), md.data()));
+            for (size_t k = 0; k < m; k++) {
+                const float* d = md.data() + k * (size_t)Nd;
+                const float maxTransDis = (float)(SQRT3 / 2.0 * items[lo + k].w);
+                float fu = 0, fl = 0;
+                for (int i = 0; i < Nd; i++) fu += d[i] * d[i];
+                for (int i = 0; i < Nd; i++) { const float dis = d[i] - maxTransDis; if (dis > 0) fl += dis * dis; }
+                both[lo + k] = fu; both[n + lo + k] = fl;
+            }
+        } else {
+            dev->check(icpx_bnb_eval(dev->ctx(), items.data() + lo, m, both.data() + lo, both.data() + n + lo, nullptr));
+        }
+    }
+    if (comm.world > 1) {
+        if (!comm.allreduce_sum_host) throw IcpxFailure(ICPX_EINVAL, "Collective without allreduce_sum_host");
+        comm.allreduce_sum_host(both.data(), (int)(2 * n), comm.user);
+    }
+    for (size_t k = 0; k < n; k++) { ub[k] = (float)both[k]; lb[k] = (float)both[n + k]; }
+}
+
+// One inner (translation) search: the state of GoIcp::innerBnB between two bound evaluations.
+struct GoIcp::Search {
+    float R[9];
+    int level;                 // -1: upper-bound form
+    std::priority_queue<TransNode> que;
+    float optErrorT;
+    TransNode best;
+    bool have_best = false, done = false;
+    std::vector<TransNode> pending;   // children awaiting their bounds, in evaluation order
+};
+
+void GoIcp::run_searches(std::vector<Search>& ss) {
+    std::vector<icpx_bnb_item> items;
+    std::vector<float> ub, lb;
+    const int width = std::max(1, frontier_width);
+    for (;;) {
+        items.clear();
+        for (Search& s : ss) {
+            s.pending.clear();
+            if (s.done) continue;
+            if (s.que.empty()) { s.done = true; continue; }
+            for (int k = 0; k < width && !s.que.empty(); k++) {
+                const TransNode parent = s.que.top(); s.que.pop();
+                TransNode node;
+                node.w = (float)(parent.w / 2.0);
+                for (int j = 0; j < 8; j++) {
+                    node.x = parent.x + (j & 1) * node.w;
+                    node.y = parent.y + (j >> 1 & 1) * node.w;
+                    node.z = parent.z + (j >> 2 & 1) * node.w;
+                    node.lb = node.ub = 0;
+                    s.pending.push_back(node);
+                    icpx_bnb_item it;
+                    std::memcpy(it.R, s.R, sizeof it.R);
+                    it.x = node.x; it.y = node.y; it.z = node.z; it.w = node.w; it.level = s.level;
+                    items.push_back(it);
+                }
+            }
+        }
+        if (items.empty()) break;
+        eval_items(items, ub, lb);
+        size_t pos = 0;
+        for (Search& s : ss) {
+            for (size_t k = 0; k < s.pending.size(); k++, pos++) {
+                if (s.done) continue;           // an earlier child of this batch ended the search
+                TransNode node = s.pending[k];
+                const float u = ub[pos], l = lb[pos];
+                if (u < s.optErrorT) { s.optErrorT = u; s.best = node; s.have_best = true; }
+                if (l >= s.optErrorT) continue;
+                node.lb = l; node.ub = u;
+                if (s.optErrorT - node.lb < sseThresh) { s.done = true; continue; }
+                s.que.push(node);
+            }
+        }
+    }
+}
+
+float GoIcp::innerBnB(float* maxDistL, TransNode* transOut) {
+    std::vector<Search> ss(1);
+    Search& s = ss[0];
+    std::memcpy(s.R, R_, sizeof R_);
+    s.level = cur_level_of(maxDistL);
+    s.que.push(InitTrans);
+    s.optErrorT = optError;
+    const int keep = frontier_width;
+    frontier_width = 1;                 // the reference pops one parent at a time
+    run_searches(ss);
+    frontier_width = keep;
+    if (transOut && s.have_best) *transOut = s.best;
+    return s.optErrorT;
+}
+
+// Rodrigues matrix of the cube centre in float (src/GoIcp.cpp:243-261). Returns false when t == 0.
+static bool rotation_of(float v1, float v2, float v3, float R[9]) {
+    const float t = std::sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+    if (!(t > 0)) { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0); return false; }
+    v1 /= t; v2 /= t; v3 /= t;
+    const float ct = std::cos(t), ct2 = 1 - ct, st = std::sin(t);
+    const float tmp121 = v1 * v2 * ct2, tmp122 = v3 * st;
+    const float tmp131 = v1 * v3 * ct2, tmp132 = v2 * st;
+    const float tmp231 = v2 * v3 * ct2, tmp232 = v1 * st;
+    R[0] = ct + v1 * v1 * ct2; R[1] = tmp121 - tmp122; R[2] = tmp131 + tmp132;
+    R[3] = tmp121 + tmp122; R[4] = ct + v2 * v2 * ct2; R[5] = tmp231 - tmp232;
+    R[6] = tmp131 - tmp132; R[7] = tmp231 + tmp232; R[8] = ct + v3 * v3 * ct2;
+    return true;
+}
+
+float GoIcp::OuterBnB() {
+    std::priority_queue<RotNode> que;
+    rot_pops = inner_evals = launches = 0;
+
+    // initial error: identity pose, sequential float sum (src/GoIcp.cpp:159-172)
+    {
+        Matrix4d I = Matrix4d::Identity();
+        dev->check(icpx_goicp_residuals(dev->ctx(), I.m, minDis.data()));
+        optError = 0;
+        for (int i = 0; i < Nd; i++) optError += minDis[i] * minDis[i];
+        initError = optError;
+    }
+    Matrix4d tmpMat = optMat;
+    float error = runICP(tmpMat);
+    icpError = error;
+    if (error < optError) { optError = error; optMat = tmpMat; }
+    final_lb = 0;
+    if (!run_bnb) return 0.0f;   // the committed code returns here (src/GoIcp.cpp:189)
+
+    que.push(InitRot);
+    for (;;) {
+        if (que.empty()) break;
+        const RotNode parent = que.top(); que.pop();
+        final_lb = parent.lb;
+        if (optError - parent.lb < sseThresh) break;
+        if (max_rot_pops > 0 && rot_pops >= max_rot_pops) break;
+        rot_pops++;
+
+        struct Child { RotNode node; float R[9]; };
+        std::vector<Child> kids;
+        RotNode nodeRot;
+        nodeRot.l = parent.l + 1;
+        nodeRot.w = parent.w / 2;
+        nodeRot.lb = nodeRot.ub = 0;
+        for (int j = 0; j < 8; j++) {
+            nodeRot.a = parent.a + (j & 1) * nodeRot.w;
+            nodeRot.b = parent.b + (j >> 1 & 1) * nodeRot.w;
+            nodeRot.c = parent.c + (j >> 2 & 1) * nodeRot.w;
+            const float v1 = nodeRot.a + nodeRot.w / 2, v2 = nodeRot.b + nodeRot.w / 2, v3 = nodeRot.c + nodeRot.w / 2;
+            if (std::sqrt(v1 * v1 + v2 * v2 + v3 * v3) - SQRT3 * nodeRot.w / 2 > PI) continue;   // outside the pi-ball
+            Child c;
+            c.node = nodeRot;
+            rotation_of(v1, v2, v3, c.R);
+            kids.push_back(c);
+        }
+
+        std::vector<Search> ss;
+        if (batched) {
+            // the 2 x |kids| inner searches advance together; each starts from the current optError
+            ss.resize(2 * kids.size());
+            for (size_t k = 0; k < kids.size(); k++)
+                for (int form = 0; form < 2; form++) {
+                    Search& s = ss[2 * k + form];
+                    std::memcpy(s.R, kids[k].R, sizeof s.R);
+                    s.level = form == 0 ? -1 : std::min(kids[k].node.l, MAXROTLEVEL - 1);
+                    s.que.push(InitTrans);
+                    s.optErrorT = optError;
+                }
+            run_searches(ss);
+        }
+
+        bool finished = false;
+        for (size_t k = 0; k < kids.size() && !finished; k++) {
+            RotNode node = kids[k].node;
+            const float* R = kids[k].R;
+            std::memcpy(R_, R, sizeof R_);
+            TransNode nodeTrans = InitTrans;
+            float ub;
+            if (batched) { ub = ss[2 * k].optErrorT; if (ss[2 * k].have_best) nodeTrans = ss[2 * k].best; }
+            else ub = innerBnB(nullptr, &nodeTrans);
+            if (ub < optError) {
+                optError = ub;
+                optNodeRot = node;
+                optNodeTrans = nodeTrans;
+                optMat = Matrix4d::Identity();
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) optMat(r, c) = R[3 * r + c];
+                optMat(0, 3) = optNodeTrans.x + optNodeTrans.w / 2;
+                optMat(1, 3) = optNodeTrans.y + optNodeTrans.w / 2;
+                optMat(2, 3) = optNodeTrans.z + optNodeTrans.w / 2;
+                tmpMat = optMat;
+                error = runICP(tmpMat);
+                if (error < optError) { optError = error; optMat = tmpMat; }
+                // drop queued rotation cubes that can no longer improve (src/GoIcp.cpp:317-328)
+                std::priority_queue<RotNode> keep;
+                while (!que.empty()) {
+                    const RotNode n = que.top(); que.pop();
+                    if (n.lb < optError) keep.push(n); else break;
+                }
+                que = keep;
+            }
+            const int lvl = std::min(node.l, MAXROTLEVEL - 1);
+            float lb;
+            if (batched) lb = ss[2 * k + 1].optErrorT;
+            else lb = innerBnB(maxRotDist[lvl], nullptr);
+            if (batched && lb > optError) lb = optError;   // a search started before optError improved
+            if (lb >= optError) continue;
+            node.lb = lb; node.ub = ub;
+            if (optError - parent.lb < sseThresh) { finished = true; break; }
+            que.push(node);
+        }
+        if (finished) break;
+    }
+    return optError;
+}
+
+ICP_res GoIcp::registration() {
+    Init();
+    OuterBnB();
+    clear();
+    ICP_res ans;
+    ans.resN3.data.resize((size_t)Nd * 3);
+    for (int i = 0; i < Nd; i++) {
+        const Point3f& s = pData->points[i];
+        const double p[3] = {(double)s.x, (double)s.y, (double)s.z};
+        apply4(optMat, p, &ans.resN3.data[3 * (size_t)i]);
+    }
+    ans.transMat = optMat;   // the reference leaves this field unset (src/GoIcp.cpp:542-547)
+    return ans;
+}
+
+}  // namespace icp
+
+// =================================================================================================
+// extern "C" driver surface over the classes, for Python (tests, bench) — handles are opaque.
+// =================================================================================================
+using namespace icp;
+
+namespace {
+thread_local std::string g_err;
+template <class F> int guard(F&& f) {
+    try { f(); return 0; }
+    catch (const IcpxFailure& e) { g_err = e.what(); return e.code; }
+    catch (const std::exception& e) { g_err = e.what(); return -100; }
+}
+PointCloudTPtr make_cloud(const float* xyz, size_t n) {
+    auto c = std::make_shared<PointCloudT>();
+    c->points.resize(n);
+    for (size_t i = 0; i < n; i++) c->points[i] = Point3f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    return c;
+}
+struct HCollective {
+    void (*allreduce_host)(double*, int) = nullptr;
+    static void tramp(double* p, int n, void* user) { ((HCollective*)user)->allreduce_host(p, n); }
+};
+struct HIcp { DevicePtr dev; PointCloudTPtr src, tgt; std::unique_ptr<SingleThreadIcp> icp; HCollective hc; };
+struct HGo { DevicePtr dev; PointCloudTPtr model, data; std::unique_ptr<GoIcp> go; HCollective hc; };
+struct HLdt { DevicePtr dev; PointCloudTPtr cloud; std::unique_ptr<LDT> ldt; };
+struct HKd { DevicePtr dev; PointCloudTPtr cloud; std::unique_ptr<KDTree> kd; };
+}  // namespace
+
+extern "C" {
+
+const char* icpxh_last_error() { return g_err.c_str(); }
+
+void icpxh_svd3(const double* A9, double* U9, double* s3, double* V9) {
+    Matrix3d A, U, V;
+    std::memcpy(A.m, A9, sizeof A.m);
+    svd3(A, U, s3, V);
+    std::memcpy(U9, U.m, sizeof U.m); std::memcpy(V9, V.m, sizeof V.m);
+}
+
+void icpxh_kabsch(const double* H9, double* R9) {
+    Matrix3d H;
+    std::memcpy(H.m, H9, sizeof H.m);
+    const Matrix3d R = kabsch_rotation(H);
+    std::memcpy(R9, R.m, sizeof R.m);
+}
+
+// ---- KDTree
+void* icpxh_kdtree_new(int device, const float* tgt, size_t n) {
+    HKd* h = new HKd;
+    if (guard([&] { h->dev = std::make_shared<Device>(device); h->cloud = make_cloud(tgt, n); h->kd.reset(new KDTree(h->cloud, 3, h->dev)); })) { delete h; return nullptr; }
+    return h;
+}
+void icpxh_kdtree_free(void* p) { delete (HKd*)p; }
+int icpxh_kdtree_get_closest(void* p, const double* q, size_t n, int32_t* idx, double* d2) {
+    return guard([&] { HKd* h = (HKd*)p; if (n == 1) { Vector3d v; v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; idx[0] = h->kd->get_closest(v); if (d2) h->kd->get_closest(q, 1, idx, d2); } else h->kd->get_closest(q, n, idx, d2); });
+}
+int icpxh_kdtree_distance(void* p, const float* q, size_t n, float* out) {
+    return guard([&] { HKd* h = (HKd*)p; if (n == 1) out[0] = h->kd->Distance(q[0], q[1], q[2]); else h->kd->Distance(q, n, out); });
+}
+
+// ---- LDT
+void* icpxh_ldt_new(int device, const float* tgt, size_t n, uint32_t div) {
+    HLdt* h = new HLdt;
+    if (guard([&] { h->dev = std::make_shared<Device>(device); h->cloud = make_cloud(tgt, n); h->ldt.reset(new LDT(h->cloud, div, 2, h->dev)); })) { delete h; return nullptr; }
+    return h;
+}
+void icpxh_ldt_free(void* p) { delete (HLdt*)p; }
+int icpxh_ldt_info(void* p, float* min3, float* cellLen, uint32_t* div, uint64_t* occupied) {
+    HLdt* h = (HLdt*)p;
+    min3[0] = h->ldt->_min.x; min3[1] = h->ldt->_min.y; min3[2] = h->ldt->_min.z;
+    *cellLen = h->ldt->cellLen; *div = h->ldt->div; *occupied = h->ldt->occupied;
+    return 0;
+}
+int icpxh_ldt_distance(void* p, const float* q, size_t n, float* out) {
+    return guard([&] { HLdt* h = (HLdt*)p; if (n == 1) out[0] = h->ldt->Distance(q[0], q[1], q[2]); else h->ldt->Distance(q, n, out); });
+}
+int icpxh_ldt_grid(void* p, float* g_out, int32_t* sq_out) {
+    return guard([&] {
+        HLdt* h = (HLdt*)p;
+        if (sq_out) std::memcpy(sq_out, h->ldt->squared().data(), h->ldt->squared().size() * sizeof(int32_t));
+        if (g_out) std::memcpy(g_out, h->ldt->grid().data(), h->ldt->grid().size() * sizeof(float));
+    });
+}
+
+// ---- SingleThreadIcp
+void* icpxh_icp_new(int device, const float* src, size_t ns, const float* tgt, size_t nt, int iters) {
+    HIcp* h = new HIcp;
+    if (guard([&] {
+            h->dev = std::make_shared<Device>(device);
+            h->src = make_cloud(src, ns); h->tgt = make_cloud(tgt, nt);
+            h->icp.reset(new SingleThreadIcp(h->src, h->tgt, iters, h->dev));
+        })) { delete h; return nullptr; }
+    return h;
+}
+void icpxh_icp_free(void* p) { delete (HIcp*)p; }
+// world > 1: this handle holds one slice of the source; allreduce sums `n` host doubles over the ranks in place.
+int icpxh_icp_set_collective(void* p, int rank, int world, void (*allreduce)(double*, int)) {
+    return guard([&] {
+        HIcp* h = (HIcp*)p;
+        h->hc.allreduce_host = allreduce;
+        h->icp->comm.rank = rank; h->icp->comm.world = world; h->icp->comm.user = &h->hc;
+        h->icp->comm.allreduce_sum_host = &HCollective::tramp;
+        h->icp->setSource(h->src);   // refresh Nd_global
+    });
+}
+// guess16 / T_out16 row-major; per_iter_T (iters x 16), mse (iters) and resN3 (ns x 3) may be NULL.
+int icpxh_icp_registration(void* p, const double* guess16, double* T_out16, double* per_iter_T, double* mse, double* resN3, int32_t* idx_last) {
+    return guard([&] {
+        HIcp* h = (HIcp*)p;
+        Matrix4d g;
+        std::memcpy(g.m, guess16, sizeof g.m);
+        h->icp->keep_correspondences = idx_last != nullptr;
+        ICP_res r = h->icp->registration(g, h->src);
+        std::memcpy(T_out16, r.transMat.m, sizeof r.transMat.m);
+        const int it = h->icp->max_iter;
+        if (per_iter_T) for (int k = 0; k < it; k++) std::memcpy(per_iter_T + 16 * k, h->icp->T_trace[k].m, 16 * sizeof(double));
+        if (mse) for (int k = 0; k < it; k++) mse[k] = h->icp->mse_trace[k];
+        if (resN3) std::memcpy(resN3, r.resN3.data.data(), r.resN3.data.size() * sizeof(double));
+        if (idx_last) std::memcpy(idx_last, h->icp->Neighbour.pointsPARA.data(), sizeof(int32_t) * h->icp->Nd);
+    });
+}
+
+// ---- GoIcp
+void* icpxh_goicp_new(int device, const float* model, size_t nm, const float* data, size_t nd, double mse, uint32_t dt_div) {
+    HGo* h = new HGo;
+    if (guard([&] {
+            h->dev = std::make_shared<Device>(device);
+            h->model = make_cloud(model, nm); h->data = make_cloud(data, nd);
+            h->go.reset(new GoIcp(h->model, h->data, 10000, mse, h->dev, dt_div));
+        })) { delete h; return nullptr; }
+    return h;
+}
+void icpxh_goicp_free(void* p) { delete (HGo*)p; }
+int icpxh_goicp_options(void* p, int run_bnb, int batched, int parity_sums, int frontier_width, long long max_rot_pops) {
+    HGo* h = (HGo*)p;
+    h->go->run_bnb = run_bnb != 0; h->go->batched = batched != 0; h->go->parity_sums = parity_sums != 0;
+    h->go->frontier_width = frontier_width; h->go->max_rot_pops = max_rot_pops;
+    return 0;
+}
+int icpxh_goicp_set_collective(void* p, int rank, int world, void (*allreduce)(double*, int)) {
+    HGo* h = (HGo*)p;
+    h->hc.allreduce_host = allreduce;
+    h->go->comm.rank = rank; h->go->comm.world = world; h->go->comm.user = &h->hc;
+    h->go->comm.allreduce_sum_host = &HCollective::tramp;
+    return 0;
+}
+// stats8: optError, initError, icpError, rot_pops, inner_evals, final_lb, launches, sseThresh
+int icpxh_goicp_registration(void* p, double* optMat16, double* stats8, double* resN3) {
+    return guard([&] {
+        HGo* h = (HGo*)p;
+        ICP_res r = h->go->registration();
+        std::memcpy(optMat16, h->go->optMat.m, 16 * sizeof(double));
+        stats8[0] = h->go->optError; stats8[1] = h->go->initError; stats8[2] = h->go->icpError;
+        stats8[3] = (double)h->go->rot_pops; stats8[4] = (double)h->go->inner_evals; stats8[5] = h->go->final_lb;
+        stats8[6] = (double)h->go->launches; stats8[7] = h->go->sseThresh;
+        if (resN3) std::memcpy(resN3, r.resN3.data.data(), r.resN3.data.size() * sizeof(double));
+    });
+}
+// A single innerBnB call under rotation R9 with the given optError (exposes the member for parity tests).
+int icpxh_goicp_inner(void* p, const float* R9, int level, float optError, float* result, float* trans4) {
+    return guard([&] {
+        HGo* h = (HGo*)p;
+        GoIcp& g = *h->go;
+        if (!g.maxRotDist) g.Init();
+        g.optError = optError;
+        TransNode t = g.InitTrans;
+        g.setRotation(R9);
+        *result = g.innerBnB(level < 0 ? nullptr : g.maxRotDist[level], &t);
+        trans4[0] = t.x; trans4[1] = t.y; trans4[2] = t.z; trans4[3] = t.w;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// C++ host classes with the shapes of the reference's registration API, running on the icpx C ABI.
+//
+//   icp::Registration / icp::ICP_res   src/Registration.hpp:10-24
+//   icp::KDTree                        src/kdtree.cpp:30-152        (get_closest, Distance)
+//   icp::LDT                           src/testLDT.cpp:26-37        (Distance; public g, _min, cellLen, div)
+//   icp::SingleThreadIcp               src/SingleThreadIcp.cpp:46-94
+//   icp::GoIcp                         src/GoIcp.cpp:44-79
+//
+// PCL, Eigen and boost are not available, so the cloud and matrix types are small stand-alone structs
+// with the members the reference's callers touch (points, x/y/z, operator()(r,c), rows()).
+// Only include/icpx.h is used underneath: no HIP, no torch.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "icpx.h"
+
+namespace icp {
+
+struct Point3f {            // 16-byte point like pcl::PointXYZ (src/common.hpp:28)
+    float x = 0, y = 0, z = 0, pad = 1.0f;
+    Point3f() = default;
+    Point3f(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+};
+
+struct PointCloudT {
+    std::vector<Point3f> points;
+    size_t size() const { return points.size(); }
+};
+using PointCloudTPtr = std::shared_ptr<PointCloudT>;
+
+struct Vector3d {
+    double v[3] = {0, 0, 0};
+    double& operator[](int i) { return v[i]; }
+    double operator[](int i) const { return v[i]; }
+};
+
+struct Matrix3d {
+    double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double& operator()(int r, int c) { return m[3 * r + c]; }
+    double operator()(int r, int c) const { return m[3 * r + c]; }
+};
+
+struct Matrix4d {           // row-major storage, (row, col) access like Eigen
+    double m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double& operator()(int r, int c) { return m[4 * r + c]; }
+    double operator()(int r, int c) const { return m[4 * r + c]; }
+    static Matrix4d Identity() { return Matrix4d(); }
+    Matrix4d operator*(const Matrix4d& o) const;
+};
+
+struct MatrixN3 {           // N x 3 doubles, row-major (stands in for Eigen::MatrixXd resN3)
+    std::vector<double> data;
+    size_t rows() const { return data.size() / 3; }
+    size_t cols() const { return 3; }
+    double& operator()(size_t r, size_t c) { return data[3 * r + c]; }
+    double operator()(size_t r, size_t c) const { return data[3 * r + c]; }
+};
+
+struct ICP_res {            // src/Registration.hpp:10-14
+    MatrixN3 resN3;
+    Matrix4d transMat;
+};
+
+class Registration {        // src/Registration.hpp:17-24
+public:
+    virtual ~Registration() {}
+    virtual void setTarget(PointCloudTPtr _target) = 0;
+    virtual ICP_res registration(Matrix4d&) = 0;
+};
+
+struct IcpxFailure : std::runtime_error {
+    int code;
+    IcpxFailure(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+// Shared handle on one icpx context (one GPU). Classes built on the same Device share the target
+// cloud, its search grid and its distance transform.
+class Device {
+public:
+    explicit Device(int device = 0);
+    ~Device();
+    Device(const Device&) = delete;
+    Device& operator=(const Device&) = delete;
+    icpx_ctx* ctx() const { return ctx_; }
+    void check(int rc) const;   // throws IcpxFailure with icpx_last_error
+    const void* target_tag = nullptr;   // identity of the cloud last given to icpx_set_target
+    uint32_t edt_div = 0;               // resolution of the EDT built for that target (0 = none)
+private:
+    icpx_ctx* ctx_ = nullptr;
+};
+using DevicePtr = std::shared_ptr<Device>;
+
+// Optional hooks that make the host loops collective over several processes (one per GPU). Each
+// process holds a slice of the source points (ICP) or evaluates a slice of every bound batch (Go-ICP).
+struct Collective {
+    int rank = 0, world = 1;
+    void* user = nullptr;
+    // in-place sum over ranks of n doubles that live in DEVICE memory of this rank's GPU
+    void (*allreduce_sum_dev)(double* dev, int n, void* user) = nullptr;
+    // in-place sum over ranks of n doubles in HOST memory
+    void (*allreduce_sum_host)(double* host, int n, void* user) = nullptr;
+};
+
+// 3x3 helpers (host side of best_fit_transform, src/SingleThreadIcp.cpp:249-272)
+void svd3(const Matrix3d& A, Matrix3d& U, double sig[3], Matrix3d& V);
+Matrix3d kabsch_rotation(const Matrix3d& H);
+
+class KDTree {              // src/kdtree.cpp:30-152
+public:
+    KDTree(const PointCloudTPtr& cloudptr, int _dims = 3, DevicePtr dev = nullptr);
+    int get_closest(const Vector3d& x);                       // src/kdtree.cpp:107-122
+    float Distance(float x0, float x1, float x2);             // src/kdtree.cpp:91-105
+    // batch forms of the two calls above (n queries, row-major n x 3)
+    void get_closest(const double* q, size_t n, int32_t* idx, double* d2 = nullptr);
+    void Distance(const float* q, size_t n, float* out);
+    int dims;
+    PointCloudTPtr target;
+    DevicePtr dev;
+};
+
+class LDT {                 // src/testLDT.cpp:26-37
+public:
+    LDT(const PointCloudTPtr&, uint32_t _div = 300, int _core = 2, DevicePtr dev = nullptr);
+    float Distance(float, float, float);                      // src/testLDT.cpp:235-290
+    void Distance(const float* q, size_t n, float* out);      // batch form
+    const std::vector<int32_t>& squared();                    // the int32 squared grid, [x][y][z]
+    const std::vector<float>& grid();                         // g = sqrt(squared), as the reference stores it
+    Point3f _min, _max;
+    uint32_t div;
+    float cellLen;
+    int CORES;                                                // kept for signature parity; unused
+    uint64_t occupied = 0;
+    DevicePtr dev;
+private:
+    std::vector<int32_t> sq_;
+    std::vector<float> g_;
+};
+
+struct Correspondance {     // src/SingleThreadIcp.cpp:37-44
+    std::vector<int> pointsPARA;
+    Matrix3d covariance;
+};
+
+class SingleThreadIcp {     // src/SingleThreadIcp.cpp:46-94
+public:
+    SingleThreadIcp(PointCloudTPtr _s, PointCloudTPtr _t, int _iter = 10, DevicePtr dev = nullptr);
+    virtual ~SingleThreadIcp() {}
+    void setTarget(PointCloudTPtr _target);
+    void setSource(const PointCloudTPtr _source);
+    virtual ICP_res registration(Matrix4d&, const PointCloudTPtr&);
+
+    void kdtree_search();          // transform + NN + sums on the GPU (src/SingleThreadIcp.cpp:186-214)
+    void cal_covarance();          // means and H from the sums (:216-247)
+    Matrix4d& best_fit_transform();   // SVD -> T, accumulates finMat (:249-290)
+
+    PointCloudTPtr source, target;
+    int max_iter;
+    Correspondance Neighbour;
+    int Nd, Nm;
+    Matrix4d T;                    // last per-iteration transform
+    Matrix4d finMat;               // accumulated transform applied to the source on the GPU
+    Vector3d mean_tar, mean_tmpdata;
+    bool keep_correspondences = false;   // fill Neighbour.pointsPARA every iteration (costs a device->host copy)
+    std::vector<double> mse_trace;       // sum |p - q|^2 / Nd BEFORE each update (the NN residual)
+    std::vector<Matrix4d> T_trace;       // per-iteration T
+    Collective comm;                     // world > 1: this object holds one slice of the source
+    long long Nd_global = 0;             // total source points over all ranks (= Nd when world == 1)
+    DevicePtr dev;
+private:
+    double sums_[ICPX_NSUMS];
+    void ensure_target();
+};
+
+struct RotNode {            // src/GoIcp.cpp:25-33
+    float a, b, c, w;
+    double lb, ub;
+    int l;
+    friend bool operator<(const RotNode& n1, const RotNode& n2) { return n1.lb > n2.lb; }
+};
+
+struct TransNode {          // src/GoIcp.cpp:35-42
+    float x, y, z, w;
+    double lb, ub;
+    friend bool operator<(const TransNode& n1, const TransNode& n2) { return n1.lb > n2.lb; }
+};
+
+class GoIcp {               // src/GoIcp.cpp:44-79
+public:
+    GoIcp(PointCloudTPtr pModel, PointCloudTPtr pData, int iter = 1e4, double _mse = 0.001, DevicePtr dev = nullptr,
+          uint32_t dt_div = 300);
+    ~GoIcp();
+    void Init();                                   // src/GoIcp.cpp:459-489
+    void clear();                                  // :529-535
+    void setTarget(PointCloudTPtr _target) { pModel = _target; }
+    ICP_res registration();                        // :537-548
+    float runICP(Matrix4d&);                       // :106-139
+    float innerBnB(float* maxDistL, TransNode* transOut);   // :353-457 (maxDistL must be NULL or maxRotDist[level])
+    float OuterBnB();                              // :142-350 with the search after the initial ICP enabled
+    // The reference's innerBnB reads the rotated cloud pDataTemp that OuterBnB prepared (:264-272); here
+    // the rotation itself is the state, and the bound kernel rotates on the fly. R is row-major 3x3.
+    void setRotation(const float R[9]) { for (int i = 0; i < 9; i++) R_[i] = R[i]; }
+
+    PointCloudTPtr pModel, pData;
+    int Nd, Nm;
+    float optError;
+    Matrix4d optMat;
+    RotNode optNodeRot;
+    TransNode optNodeTrans;
+    float mseThresh, sseThresh;
+    RotNode InitRot;
+    TransNode InitTrans;
+    float** maxRotDist = nullptr;                  // [ICPX_MAXROTLEVEL][Nd], host copy of the device table
+    std::vector<float> minDis;
+    SingleThreadIcp icp;
+    int ITER;
+
+    // Search controls that the reference does not have.
+    bool run_bnb = true;          // false: stop after the initial ICP, like the committed early return (src/GoIcp.cpp:189)
+    bool batched = true;          // true: the 2 x 8 inner searches of one rotation parent advance in lock-step, one launch per step
+    bool parity_sums = false;     // true: bounds are the reference's sequential float sums of the per-point distances
+    int frontier_width = 1;       // translation parents popped per inner search and step (batched mode)
+    long long max_rot_pops = 0;   // 0 = unlimited
+    Collective comm;              // world > 1: every bound batch is split over the ranks
+    // statistics
+    long long rot_pops = 0, inner_evals = 0, launches = 0;
+    float initError = 0, icpError = 0;
+    double final_lb = 0;
+    DevicePtr dev;
+
+private:
+    struct Search;
+    float R_[9];                                   // rotation of the current cube (innerBnB operates on it)
+    int cur_level_of(const float* maxDistL) const;
+    void eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub, std::vector<float>& lb);
+    void run_searches(std::vector<Search>& ss);
+};
+
+}  // namespace icp

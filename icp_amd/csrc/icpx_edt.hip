@@ -230,26 +230,59 @@ __global__ void k_edt_lookup(const int* __restrict__ sq, int div, float mnx, flo
 
 }  // namespace
 
-int icpx_edt_run(icpx_ctx* ctx) {
+// ev: NULL, or ICPX_EDT_NSTAGES + 1 events recorded around the stages (clear, splat, census, pass zy, pass x).
+static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
     const int div = (int)ctx->div, W = ctx->edt_words;
     const int nchunk = (div + 63) / 64;
     hipStream_t s = ctx->stream;
+    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[0], s));
     ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_bits.p, 0, (size_t)div * div * W * sizeof(u64), s));
     ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_counters.p, 0, 4 * sizeof(u64), s));
+    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(k_edt_splat, dim3((unsigned)((ctx->nt + 255) / 256)), dim3(256), 0, s, ctx->tgt_xyz.as<float>(), ctx->nt,
                        ctx->edt_min[0], ctx->edt_min[1], ctx->edt_min[2], ctx->edt_cell, div, W, ctx->edt_bits.as<u64>(),
                        ctx->edt_counters.as<u64>());
+    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(k_edt_census, dim3(div), dim3(64), 0, s, ctx->edt_bits.as<u64>(), div, W, ctx->edt_rowlist.as<unsigned short>(),
                        ctx->edt_rowcnt.as<int>(), ctx->edt_counters.as<u64>());
     hipLaunchKernelGGL(k_edt_planes, dim3(1), dim3(64), 0, s, ctx->edt_rowcnt.as<int>(), div, ctx->edt_planelist.as<unsigned short>(),
                        ctx->edt_counters.as<u64>());
+    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[3], s));
     hipLaunchKernelGGL(k_edt_pass_zy, dim3(div * nchunk), dim3(64), (size_t)ctx->edt_cap_zy * 64 * 4, s, ctx->edt_bits.as<u64>(),
                        ctx->edt_rowlist.as<unsigned short>(), ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), div, W, nchunk,
                        ctx->edt_cap_zy);
+    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(k_edt_pass_x, dim3(div * nchunk), dim3(64), (size_t)ctx->edt_cap_x * 64 * 8, s, ctx->edt_plane.as<int>(),
                        ctx->edt_planelist.as<unsigned short>(), ctx->edt_counters.as<u64>(), ctx->edt_sq.as<int>(), div, nchunk,
                        ctx->edt_cap_x);
+    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[5], s));
     return icpx_launch_check(ctx, "EDT kernels");
+}
+
+int icpx_edt_run(icpx_ctx* ctx) { return edt_run_impl(ctx, nullptr); }
+
+extern "C" int icpx_edt_rebuild_timed(icpx_ctx* ctx, int reps, float stage_ms[ICPX_EDT_NSTAGES]) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_rebuild_timed: no EDT has been built yet");
+    if (reps < 1 || !stage_ms) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_rebuild_timed: bad arguments");
+    ICPX_TRY(icpx_bind(ctx));
+    std::vector<hipEvent_t> ev((size_t)reps * (ICPX_EDT_NSTAGES + 1));
+    for (auto& e : ev) ICPX_CHECK_HIP(ctx, hipEventCreate(&e));
+    int rc = ICPX_OK;
+    for (int r = 0; r < reps && rc == ICPX_OK; r++) rc = edt_run_impl(ctx, ev.data() + (size_t)r * (ICPX_EDT_NSTAGES + 1));
+    if (rc == ICPX_OK) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e)); rc = ICPX_EHIP; }
+    }
+    for (int k = 0; k < ICPX_EDT_NSTAGES; k++) stage_ms[k] = 0.f;
+    for (int r = 0; r < reps && rc == ICPX_OK; r++)
+        for (int k = 0; k < ICPX_EDT_NSTAGES; k++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[(size_t)r * (ICPX_EDT_NSTAGES + 1) + k], ev[(size_t)r * (ICPX_EDT_NSTAGES + 1) + k + 1]);
+            stage_ms[k] += ms;
+        }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 static int edt_prepare(icpx_ctx* ctx, uint32_t div) {

@@ -1,0 +1,189 @@
+"""Python handles on the C++ host classes of csrc/host/icpx_host.hpp (KDTree, LDT, SingleThreadIcp,
+GoIcp) and the 3x3 host algebra. The classes keep the reference's names and member meaning
+(src/kdtree.cpp, src/testLDT.cpp, src/SingleThreadIcp.cpp, src/GoIcp.cpp); everything per-point runs
+on the GPU through the C ABI.
+"""
+import ctypes as C
+import numpy as np
+
+from .lib import host as _host, IcpxError
+
+_ALLREDUCE = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int)
+_configured = False
+
+
+def _lib():
+    global _configured
+    lib = _host()
+    if not _configured:
+        lib.icpxh_last_error.restype = C.c_char_p
+        for name in ("icpxh_kdtree_new", "icpxh_ldt_new", "icpxh_icp_new", "icpxh_goicp_new"):
+            getattr(lib, name).restype = C.c_void_p
+        lib.icpxh_kdtree_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+        lib.icpxh_ldt_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_uint32]
+        lib.icpxh_icp_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        lib.icpxh_goicp_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_uint32]
+        for name in ("icpxh_kdtree_free", "icpxh_ldt_free", "icpxh_icp_free", "icpxh_goicp_free"):
+            getattr(lib, name).argtypes = [C.c_void_p]; getattr(lib, name).restype = None
+        lib.icpxh_kdtree_get_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.icpxh_kdtree_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.icpxh_ldt_info.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        lib.icpxh_ldt_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.icpxh_ldt_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.icpxh_icp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
+        lib.icpxh_icp_registration.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        lib.icpxh_goicp_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong]
+        lib.icpxh_goicp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
+        lib.icpxh_goicp_registration.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.icpxh_goicp_inner.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        lib.icpxh_svd3.argtypes = [C.c_void_p] * 4
+        lib.icpxh_kabsch.argtypes = [C.c_void_p] * 2
+        _configured = True
+    return lib
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _ck(rc):
+    if rc != 0:
+        raise IcpxError(rc, _lib().icpxh_last_error().decode())
+
+
+def _new(ptr):
+    if not ptr:
+        raise IcpxError(-1, _lib().icpxh_last_error().decode())
+    return C.c_void_p(ptr)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def svd3(A):
+    A = np.ascontiguousarray(A, np.float64).reshape(3, 3)
+    U = np.empty((3, 3)); s = np.empty(3); V = np.empty((3, 3))
+    _lib().icpxh_svd3(_vp(A), _vp(U), _vp(s), _vp(V))
+    return U, s, V
+
+
+def kabsch_rotation(H):
+    H = np.ascontiguousarray(H, np.float64).reshape(3, 3); R = np.empty((3, 3))
+    _lib().icpxh_kabsch(_vp(H), _vp(R))
+    return R
+
+
+def kabsch_from_sums(sums, n):
+    """Per-iteration transform from the 16 sums of icpx_icp_step with plain means (no carry-over of the
+    previous target mean): used by the benchmark's synthetic ICP loop."""
+    pbar = sums[0:3] / n; qbar = sums[3:6] / n
+    H = (sums[6:15].reshape(3, 3) - np.outer(pbar, sums[3:6])) / n
+    R = kabsch_rotation(H)
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = qbar - R @ pbar
+    return T
+
+
+def make_allreduce(fn):
+    """Wrap fn(np.ndarray[float64]) -> None (in-place sum over ranks) as the C callback the host classes take."""
+    def cb(ptr, n):
+        fn(np.ctypeslib.as_array(ptr, shape=(n,)))
+    return _ALLREDUCE(cb)
+
+
+class KDTree:
+    def __init__(self, target, device=0):
+        self._t = _f32(target)
+        self._h = _new(_lib().icpxh_kdtree_new(device, _vp(self._t), self._t.shape[0]))
+
+    def get_closest(self, q, want_d2=False):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        idx = np.empty(q.shape[0], np.int32); d2 = np.empty(q.shape[0], np.float64) if want_d2 else None
+        _ck(_lib().icpxh_kdtree_get_closest(self._h, _vp(q), q.shape[0], _vp(idx), _vp(d2)))
+        return (idx, d2) if want_d2 else idx
+
+    def Distance(self, q):
+        q = _f32(q).reshape(-1, 3); out = np.empty(q.shape[0], np.float32)
+        _ck(_lib().icpxh_kdtree_distance(self._h, _vp(q), q.shape[0], _vp(out)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().icpxh_kdtree_free(self._h); self._h = None
+
+
+class LDT:
+    def __init__(self, target, div=300, device=0):
+        self._t = _f32(target)
+        self._h = _new(_lib().icpxh_ldt_new(device, _vp(self._t), self._t.shape[0], div))
+        mn = np.empty(3, np.float32); cl = C.c_float(); d = C.c_uint32(); occ = C.c_uint64()
+        _lib().icpxh_ldt_info(self._h, _vp(mn), C.byref(cl), C.byref(d), C.byref(occ))
+        self._min, self.cellLen, self.div, self.occupied = mn, np.float32(cl.value), d.value, occ.value
+
+    def Distance(self, q):
+        q = _f32(q).reshape(-1, 3); out = np.empty(q.shape[0], np.float32)
+        _ck(_lib().icpxh_ldt_distance(self._h, _vp(q), q.shape[0], _vp(out)))
+        return out
+
+    def grids(self):
+        """(g, squared): the float grid the reference exposes as LDT::g and the int32 squared grid."""
+        g = np.empty((self.div,) * 3, np.float32); sq = np.empty((self.div,) * 3, np.int32)
+        _ck(_lib().icpxh_ldt_grid(self._h, _vp(g), _vp(sq)))
+        return g, sq
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().icpxh_ldt_free(self._h); self._h = None
+
+
+class SingleThreadIcp:
+    def __init__(self, source, target, iters=10, device=0, allreduce=None, rank=0, world=1):
+        self._s, self._t = _f32(source), _f32(target)
+        self.iters = iters
+        self._h = _new(_lib().icpxh_icp_new(device, _vp(self._s), self._s.shape[0], _vp(self._t), self._t.shape[0], iters))
+        self._cb = None
+        if world > 1:
+            self._cb = make_allreduce(allreduce)
+            _ck(_lib().icpxh_icp_set_collective(self._h, rank, world, self._cb))
+
+    def registration(self, guess=None, want_points=False, want_idx=False):
+        g = np.ascontiguousarray(np.eye(4) if guess is None else guess, np.float64).reshape(16)
+        T = np.empty(16); per = np.empty((self.iters, 16)); mse = np.empty(self.iters)
+        res = np.empty((self._s.shape[0], 3)) if want_points else None
+        idx = np.empty(self._s.shape[0], np.int32) if want_idx else None
+        _ck(_lib().icpxh_icp_registration(self._h, _vp(g), _vp(T), _vp(per), _vp(mse), _vp(res), _vp(idx)))
+        return dict(T=T.reshape(4, 4), per_iter_T=per.reshape(-1, 4, 4), nn_mse=mse, resN3=res, idx_last=idx)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().icpxh_icp_free(self._h); self._h = None
+
+
+class GoIcp:
+    def __init__(self, model, data, mse=1e-3, dt_div=300, device=0, allreduce=None, rank=0, world=1):
+        self._m, self._d = _f32(model), _f32(data)
+        self._h = _new(_lib().icpxh_goicp_new(device, _vp(self._m), self._m.shape[0], _vp(self._d), self._d.shape[0], mse, dt_div))
+        self._cb = None
+        if world > 1:
+            self._cb = make_allreduce(allreduce)
+            _ck(_lib().icpxh_goicp_set_collective(self._h, rank, world, self._cb))
+
+    def options(self, run_bnb=True, batched=True, parity_sums=False, frontier_width=1, max_rot_pops=0):
+        _ck(_lib().icpxh_goicp_options(self._h, int(run_bnb), int(batched), int(parity_sums), frontier_width, max_rot_pops))
+        return self
+
+    def registration(self, want_points=False):
+        M = np.empty(16); st = np.zeros(8)
+        res = np.empty((self._d.shape[0], 3)) if want_points else None
+        _ck(_lib().icpxh_goicp_registration(self._h, _vp(M), _vp(st), _vp(res)))
+        return dict(optMat=M.reshape(4, 4), optError=np.float32(st[0]), initError=np.float32(st[1]), icpError=np.float32(st[2]),
+                    rot_pops=int(st[3]), inner_evals=int(st[4]), lb=st[5], launches=int(st[6]), sseThresh=st[7], resN3=res)
+
+    def innerBnB(self, R, level, optError):
+        R = _f32(R).reshape(9); out = C.c_float(); tr = np.empty(4, np.float32)
+        _ck(_lib().icpxh_goicp_inner(self._h, _vp(R), level, C.c_float(optError), C.byref(out), _vp(tr)))
+        return np.float32(out.value), tr
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().icpxh_goicp_free(self._h); self._h = None

@@ -114,6 +114,13 @@ int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[3], float c
  * icpx_edt_build* call are reused): the timed region of the EDT benchmark. */
 int icpx_edt_rebuild_async(icpx_ctx* ctx);
 
+/* Runs the same kernels `reps` times back to back on the stream with HIP events recorded between the
+ * stages, waits, and returns the summed duration of every stage in milliseconds: clear, splat, census,
+ * pass zy (z scan + y envelope), pass x. The reference times its constructor the same way with
+ * omp_get_wtime (src/testLDT.cpp:43, :209). */
+#define ICPX_EDT_NSTAGES 5
+int icpx_edt_rebuild_timed(icpx_ctx* ctx, int reps, float stage_ms[ICPX_EDT_NSTAGES]);
+
 /* LDT's public fields (src/testLDT.cpp:31-35): div, _min, cellLen; plus the occupied-voxel count and
  * the number of points dropped by the splat. Any output pointer may be NULL. */
 int icpx_edt_info(icpx_ctx* ctx, uint32_t* div, float min3[3], float* cell_len, uint64_t* occupied, uint64_t* dropped);

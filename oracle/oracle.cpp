@@ -331,15 +331,21 @@ void orc_kabsch_R(const double* H9, double* R9) {
 // best_fit_transform (:249-290). nn_mode 0 = the reference's kd-tree, 1 = brute force lowest index.
 // Outputs: per_iter_T (iters x 16, the per-iteration T), fin (16, finMat), mse (iters, the logged
 // mean squared residual after each update, :281-287), idx0 (optional, correspondences of iteration 0).
-int orc_icp(const float* src, int64_t nd, const float* tgt, int64_t nm, const double* guess, int iters,
-            int nn_mode, double* per_iter_T, double* fin, double* mse_out, int32_t* idx_last, int threads) {
+static int icp_impl(const float* src, int64_t nd, const float* tgt, int64_t nm, const double* guess, int iters,
+                    int nn_mode, double* per_iter_T, double* fin, double* mse_out, int32_t* idx_last, int threads,
+                    double* mean_tar_io) {
     if (nd <= 0 || nm <= 0) return -1;
     std::vector<double> tar(3 * nm), cur(3 * nd), srcd(3 * nd);
     for (int64_t i = 0; i < 3 * nm; i++) tar[i] = (double)tgt[i];
     for (int64_t i = 0; i < 3 * nd; i++) srcd[i] = (double)src[i];
+    // mean_tar is a member of the reference object: it is set by the constructor (cal_mean, :53) and
+    // then carried from one registration() call to the next (:229-231 never resets it).
     double mean_tar[3] = {0, 0, 0};
-    for (int64_t i = 0; i < nm; i++) for (int c = 0; c < 3; c++) mean_tar[c] += tar[3 * i + c];
-    for (int c = 0; c < 3; c++) mean_tar[c] /= (double)nm;
+    if (mean_tar_io && mean_tar_io[3] != 0.0) { for (int c = 0; c < 3; c++) mean_tar[c] = mean_tar_io[c]; }
+    else {
+        for (int64_t i = 0; i < nm; i++) for (int c = 0; c < 3; c++) mean_tar[c] += tar[3 * i + c];
+        for (int c = 0; c < 3; c++) mean_tar[c] /= (double)nm;
+    }
 
     void* kd = nn_mode == 0 ? orc_kdtree_build(tgt, nm) : nullptr;
     double finMat[16]; std::memcpy(finMat, guess, sizeof finMat);
@@ -384,8 +390,14 @@ int orc_icp(const float* src, int64_t nd, const float* tgt, int64_t nm, const do
     }
     if (idx_last) std::memcpy(idx_last, idx.data(), sizeof(int32_t) * nd);
     std::memcpy(fin, finMat, sizeof finMat);
+    if (mean_tar_io) { for (int c = 0; c < 3; c++) mean_tar_io[c] = mean_tar[c]; mean_tar_io[3] = 1.0; }
     if (kd) orc_kdtree_free(kd);
     return 0;
+}
+
+int orc_icp(const float* src, int64_t nd, const float* tgt, int64_t nm, const double* guess, int iters,
+            int nn_mode, double* per_iter_T, double* fin, double* mse_out, int32_t* idx_last, int threads) {
+    return icp_impl(src, nd, tgt, nm, guess, iters, nn_mode, per_iter_T, fin, mse_out, idx_last, threads, nullptr);
 }
 
 // ---- LDT ------------------------------------------------------------------------------------------
@@ -639,6 +651,7 @@ struct GoIcpState {
     DistFn D; const float* data; int64_t nd; const float* model; int64_t nm;
     std::vector<float> rotated, minDis, maxRot; float optError; float sseThresh; int threads;
     int64_t inner_evals = 0;
+    double mean_tar_state[4] = {0, 0, 0, 0};   // {mean, valid flag}: the icp member's mean_tar between runICP calls
 };
 
 // GoIcp::innerBnB (src/GoIcp.cpp:353-457).
@@ -683,7 +696,7 @@ static float inner_bnb(GoIcpState& S, const float* maxRotDistL, TransNode* trans
 // src/SingleThreadIcp.cpp:49) from a guess, then the float sequential SSE through the distance function.
 static float run_icp(GoIcpState& S, double* M, int icp_iters, int nn_mode) {
     double fin[16];
-    orc_icp(S.data, S.nd, S.model, S.nm, M, icp_iters, nn_mode, nullptr, fin, nullptr, nullptr, S.threads);
+    icp_impl(S.data, S.nd, S.model, S.nm, M, icp_iters, nn_mode, nullptr, fin, nullptr, nullptr, S.threads, S.mean_tar_state);
     std::memcpy(M, fin, sizeof fin);
     std::vector<float> err(S.nd);
 #pragma omp parallel for

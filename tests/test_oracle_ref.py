@@ -1,0 +1,73 @@
+"""CPU: the oracle against the parts of the reference that compile from their own sources
+(oracle/_ref/libref.so, built by oracle/Makefile where /root/reference exists). Skipped where that
+library is absent (the GPU box)."""
+import numpy as np
+import pytest
+
+from conftest import rigid
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref/libref.so not built (no /root/reference here)")
+    return oracle
+
+
+def test_nn_distances_equal_nanoflann(ref, bunny000, bunny045):
+    """src/nanoflann.hpp knnSearch as src/jly_icp3d.cpp:229 uses it (T = double): identical squared
+    distances; indices agree wherever the minimum is unique."""
+    T = rigid([0.1, 1, 0.3], 12.0, [0.004, -0.003, 0.002])
+    for q in (bunny000.astype(np.float64), np.ascontiguousarray(bunny000.astype(np.float64) @ T[:3, :3].T + T[:3, 3])):
+        nidx, nd2 = ref.ref_nanoflann_nn(bunny045.astype(np.float64), q)
+        bidx, bd2 = ref.nn_brute(q, bunny045)
+        kidx, kd2 = ref.KdTree(bunny045).nn(q)
+        assert np.array_equal(nd2, bd2) and np.array_equal(nd2, kd2)
+        differ = np.nonzero(nidx != bidx)[0]
+        t = bunny045.astype(np.float64)
+        for i in differ:      # only exact ties may differ
+            d = ((q[i, 0] - t[nidx[i], 0]) ** 2 + (q[i, 1] - t[nidx[i], 1]) ** 2) + (q[i, 2] - t[nidx[i], 2]) ** 2
+            assert d == bd2[i]
+        assert len(differ) <= 60
+
+
+def test_svd_and_kabsch_equal_matrix_svd(ref):
+    """src/matrix.cpp Matrix::svd (the routine north_star's host SVD refers to): same singular values and
+    the same rotation out of the Kabsch step, for the oracle's SVD and for the product's host SVD."""
+    from icp_amd import host
+    rng = np.random.default_rng(4)
+    for k in range(300):
+        H = rng.normal(size=(3, 3)) * 10 ** rng.uniform(-4, 1)
+        U, W, V = ref.ref_matrix_svd3(H)
+        assert np.abs(U @ np.diag(W) @ V.T - H).max() < 1e-12 * max(1.0, np.abs(H).max())
+        R_ref = (U @ V.T).T
+        if np.linalg.det(R_ref) < 0:
+            Vt = V.T.copy(); Vt[np.argmin(W)] *= -1; R_ref = (U @ Vt).T
+        for mine in (ref.kabsch_R(H), host.kabsch_rotation(H)):
+            assert np.abs(mine - R_ref).max() < 1e-9
+        assert np.allclose(np.sort(ref.svd3(H)[1]), np.sort(W), rtol=1e-9, atol=1e-15)
+        assert np.allclose(np.sort(host.svd3(H)[1]), np.sort(W), rtol=1e-12, atol=1e-15)
+
+
+def test_exact_edt_against_dt3d(ref, bunny000, bunny045):
+    """src/jly_3ddt.cpp DT3D (300^3 vector-propagation DT, the original Go-ICP lookup): an approximate
+    transform on a different voxelisation; the exact LDT distances agree with it within a few cells."""
+    dt = ref.RefDT3D(bunny045, expand=2.0)
+    assert dt.size == 300
+    d_ref = dt.distance(bunny000.astype(np.float64))
+    mn, cell = ref.ldt_box(bunny045, 300)
+    occ, _ = ref.ldt_splat(bunny045, 300, mn, cell)
+    sq = ref.edt_meijster(occ)
+    d_mine = ref.ldt_lookup(sq, mn, cell, bunny000)
+    cell_ref = 1.0 / dt.scale
+    assert np.abs(d_mine - d_ref).max() < 2.0 * (cell + cell_ref)
+    assert abs(np.mean(d_mine) - np.mean(d_ref)) < 0.6 * (cell + cell_ref)
+
+
+def test_icp_agrees_with_icp3d(ref, bunny000, bunny045):
+    """src/jly_icp3d.cpp ICP3D<double>::Run (nanoflann NN, Matrix::svd) for 30 fixed iterations lands in
+    the same pose as the SingleThreadIcp restatement (both carry means between iterations, in slightly
+    different ways, so agreement is at the 1e-3 level, not bitwise)."""
+    R, t, err = ref.ref_icp3d_run(bunny045.astype(np.float64), bunny000.astype(np.float64), 30)
+    mine = ref.icp(bunny000, bunny045, 30, nn_mode=0)["T"]
+    assert np.abs(mine[:3, :3] - R).max() < 2e-3 and np.abs(mine[:3, 3] - t).max() < 2e-3
