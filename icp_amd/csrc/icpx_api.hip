@@ -68,8 +68,8 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
     // Tuning knobs (LDS stack levels per lane of the two EDT envelope passes).
-    if (const char* v = getenv("ICPX_EDT_CAP_ZY")) { int c = atoi(v); if (c >= 1 && c <= 512) ctx->edt_cap_zy = c; }
-    if (const char* v = getenv("ICPX_EDT_CAP_X")) { int c = atoi(v); if (c >= 1 && c <= 256) ctx->edt_cap_x = c; }
+    if (const char* v = getenv("ICPX_EDT_CAP_ZY")) { int c = atoi(v); if (c >= 1 && c <= 104) ctx->edt_cap_zy = c; }
+    if (const char* v = getenv("ICPX_EDT_CAP_X")) { int c = atoi(v); if (c >= 1 && c <= 85) ctx->edt_cap_x = c; }
     *out = ctx;
     return ICPX_OK;
 }

@@ -51,11 +51,13 @@ struct icpx_ctx {
     int edt_words = 0;       // 64-bit words per (x,y) bit row
     float edt_min[3] = {0, 0, 0};
     float edt_cell = 0.f;
-    int edt_cap_zy = 64, edt_cap_x = 64;   // LDS stack levels per lane
+    // LDS stack levels per lane. zy: 4 B per level; x: 5 B (div <= 511) or 6 B per level. Sized so that
+    // six one-wave workgroups fit the 160 KiB of a CU (6 x 64 lanes x 80 levels x 5 B = 150 KiB).
+    int edt_cap_zy = 96, edt_cap_x = 80;
     DevBuf edt_bits;         // div*div*edt_words uint64 occupancy bits
-    DevBuf edt_rowlist;      // div x div uint16: ascending non-empty rows y of every plane x
+    DevBuf edt_rowlist;      // [x][chunk][k] 16-byte records of the non-empty rows of every plane (see k_edt_census)
     DevBuf edt_rowcnt;       // div int
-    DevBuf edt_planelist;    // div uint16 ascending non-empty planes; [div] holds nothing
+    DevBuf edt_planelist;    // int32 ascending non-empty planes, padded with the last one to a multiple of 16 plus 16
     DevBuf edt_counters;     // uint64 x 4: {occupied voxels, dropped points, nplanes, unused}
     DevBuf edt_plane;        // div^3 int32: in-plane squared distances (only non-empty planes written)
     DevBuf edt_sq;           // div^3 int32: squared EDT, [x][y][z]

@@ -51,6 +51,30 @@ def test_edt_dense_random_and_spill(gpu_ctx, oracle):
     assert gpu_ctx.edt_info()["dropped"] == dropped
 
 
+def test_edt_large_div_uses_wide_entries(gpu_ctx, oracle, bunny045):
+    """div > 511 switches the x pass to its 6-byte stack entries."""
+    _build_and_check(gpu_ctx, oracle, np.ascontiguousarray(bunny045[::3]), 520)
+
+
+@pytest.mark.parametrize("cap", ["2", "7"])
+def test_edt_spill_tier(oracle, bunny045, cap, monkeypatch):
+    """A tiny LDS capacity pushes almost every stack level into the spill tier."""
+    from icp_amd.api import Context
+    monkeypatch.setenv("ICPX_EDT_CAP_ZY", cap)
+    monkeypatch.setenv("ICPX_EDT_CAP_X", cap)
+    ctx = Context(0)
+    try:
+        _build_and_check(ctx, oracle, bunny045, 100)
+        rng = np.random.default_rng(1)
+        pts = rng.uniform(0.0, 1.0, (60000, 3)).astype(np.float32)
+        ctx.set_target(pts)
+        ctx.edt_build(72, box=(np.zeros(3, np.float32), np.float32(1.0 / 72)))
+        occ, _ = oracle.ldt_splat(pts, 72, np.zeros(3, np.float32), np.float32(1.0 / 72))
+        assert np.array_equal(ctx.edt_read(), oracle.edt_meijster(occ))
+    finally:
+        ctx.close()
+
+
 def test_edt_single_voxel_and_brute(gpu_ctx, oracle):
     pts = np.array([[0.31, 0.52, 0.77]], np.float32)
     mn = np.zeros(3, np.float32); cell = np.float32(1.0 / 40)
