@@ -20,12 +20,22 @@ int icpx_sort_reserve(icpx_ctx* ctx, size_t n);
 
 namespace {
 
+constexpr int MAXLEV = 11;
+
+// Level 0 is the cell grid itself; level l >= 1 halves every dimension (rounding up) and keeps one byte
+// per cell: non-zero when any point lies below it. The search uses the pyramid to skip empty space.
 struct GridView {
     int dx, dy, dz;
     float minx, miny, minz, h, inv;
     const int2* __restrict__ range;
     const float4* __restrict__ pts;
+    const unsigned char* __restrict__ flags;   // all levels >= 1, level l at flags + loff[l]
+    const unsigned* __restrict__ loff;          // MAXLEV offsets into flags (device memory)
+    int nlev;                                   // number of levels including level 0
 };
+
+// Cells along one axis at level l: ceil(d / 2^l).
+__device__ __forceinline__ int lev_dim(int d, int l) { return (d + (1 << l) - 1) >> l; }
 
 __device__ __forceinline__ int cell_coord(float v, float mn, float inv, int dim) {
     const float f = floorf((v - mn) * inv);
@@ -54,6 +64,23 @@ __global__ void k_gather_pts(const float4* __restrict__ src, const unsigned* __r
     if (i < n) dst[i] = src[order[i]];
 }
 
+__global__ void k_pyr_from_cells(const int2* __restrict__ range, int dx, int dy, int dz, unsigned char* __restrict__ up, int ux, int uy, int uz) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)dx * dy * dz) return;
+    const int2 r = range[i];
+    if (r.y <= r.x) return;
+    const int cz = (int)(i % dz), cy = (int)((i / dz) % dy), cx = (int)(i / ((size_t)dz * dy));
+    up[((size_t)(cx >> 1) * uy + (cy >> 1)) * uz + (cz >> 1)] = 1;
+}
+
+__global__ void k_pyr_from_flags(const unsigned char* __restrict__ lo, int dx, int dy, int dz, unsigned char* __restrict__ up, int ux, int uy, int uz) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)dx * dy * dz) return;
+    if (!lo[i]) return;
+    const int cz = (int)(i % dz), cy = (int)((i / dz) % dy), cx = (int)(i / ((size_t)dz * dy));
+    up[((size_t)(cx >> 1) * uy + (cy >> 1)) * uz + (cz >> 1)] = 1;
+}
+
 struct Best {
     double d2;
     int idx;
@@ -76,73 +103,117 @@ __device__ __forceinline__ double axis_gap2(double q, double lo, double hi, doub
     return g * g;
 }
 
-__device__ Best nn_search(const GridView& g, double qx, double qy, double qz) {
+// Squared distance from q to the box of cell (i,j,k) at a level whose cells have side `side`, shrunk by
+// the margin so that it is a valid lower bound for every point filed under that cell.
+__device__ __forceinline__ double box_lb2(double qx, double qy, double qz, double ox, double oy, double oz, double side, int i, int j,
+                                          int k, double margin) {
+    return axis_gap2(qx, ox + i * side, ox + (i + 1) * side, margin) + axis_gap2(qy, oy + j * side, oy + (j + 1) * side, margin) +
+           axis_gap2(qz, oz + k * side, oz + (k + 1) * side, margin);
+}
+
+constexpr int NN_LEVELS = MAXLEV + 1;   // per-thread walk state: one word per pyramid level plus a virtual root
+
+// Exact nearest neighbour. Fast path: the query's own cell and the 26 around it; it is final when the
+// best distance found is smaller than the distance to everything outside that 3x3x3 block. Otherwise
+// (query far from the cloud, or a large empty gap) a depth-first walk down the occupancy pyramid,
+// nearer children first, skipping empty subtrees and those whose box is farther than the best so far.
+// The walk keeps one word per level (the node being expanded and how many of its children are done),
+// in LDS at `state[level * sstride]`; `loff` are the per-level flag offsets staged in LDS.
+__device__ Best nn_search(const GridView& g, double qx, double qy, double qz, unsigned* state, int sstride, const unsigned* loff) {
     Best b{INFINITY, 0x7fffffff};
     const int cx = cell_coord((float)qx, g.minx, g.inv, g.dx), cy = cell_coord((float)qy, g.miny, g.inv, g.dy),
               cz = cell_coord((float)qz, g.minz, g.inv, g.dz);
-    scan_cell(g, (cx * g.dy + cy) * g.dz + cz, qx, qy, qz, b);
     const double h = (double)g.h;
     // Cell membership of the target points was decided in float arithmetic: a point can sit up to a few
     // float ulps outside the box of its cell. The margin makes every lower bound conservative.
     const double margin = 1e-3 * h + 1e-6 * (fabs(qx) + fabs(qy) + fabs(qz));
     const double ox = (double)g.minx, oy = (double)g.miny, oz = (double)g.minz;
-    const int rmax = max(max(max(cx, g.dx - 1 - cx), max(cy, g.dy - 1 - cy)), max(cz, g.dz - 1 - cz));
-    const double bx = fmax(fmax(ox - qx, qx - (ox + g.dx * h)) - margin, 0.0);
-    const double by = fmax(fmax(oy - qy, qy - (oy + g.dy * h)) - margin, 0.0);
-    const double bz = fmax(fmax(oz - qz, qz - (oz + g.dz * h)) - margin, 0.0);
-    for (int r = 1; r <= rmax; r++) {
-        // Lower bound over everything at Chebyshev cell distance >= r: the nearest of the six slabs.
-        // Each slab bound is combined with the distance to the grid's own box along the other two axes
-        // (bx, by, bz), which matters for queries outside the grid.
-        double ring = INFINITY;
-        if (cx + r < g.dx) { double t = fmax(fmax(ox + (cx + r) * h - qx - margin, 0.0), bx); ring = fmin(ring, t * t + by * by + bz * bz); }
-        if (cx - r >= 0)   { double t = fmax(fmax(qx - (ox + (cx - r + 1) * h) - margin, 0.0), bx); ring = fmin(ring, t * t + by * by + bz * bz); }
-        if (cy + r < g.dy) { double t = fmax(fmax(oy + (cy + r) * h - qy - margin, 0.0), by); ring = fmin(ring, bx * bx + t * t + bz * bz); }
-        if (cy - r >= 0)   { double t = fmax(fmax(qy - (oy + (cy - r + 1) * h) - margin, 0.0), by); ring = fmin(ring, bx * bx + t * t + bz * bz); }
-        if (cz + r < g.dz) { double t = fmax(fmax(oz + (cz + r) * h - qz - margin, 0.0), bz); ring = fmin(ring, bx * bx + by * by + t * t); }
-        if (cz - r >= 0)   { double t = fmax(fmax(qz - (oz + (cz - r + 1) * h) - margin, 0.0), bz); ring = fmin(ring, bx * bx + by * by + t * t); }
-        if (ring > b.d2) break;
-        const int i0 = max(cx - r, 0), i1 = min(cx + r, g.dx - 1);
-        const int j0 = max(cy - r, 0), j1 = min(cy + r, g.dy - 1);
-        const int k0 = max(cz - r, 0), k1 = min(cz + r, g.dz - 1);
-        for (int i = i0; i <= i1; i++) {
-            const double gx = axis_gap2(qx, ox + i * h, ox + (i + 1) * h, margin);
-            if (gx > b.d2) continue;
-            const bool edge_i = (i == cx - r) || (i == cx + r);
-            for (int j = j0; j <= j1; j++) {
-                const double gxy = gx + axis_gap2(qy, oy + j * h, oy + (j + 1) * h, margin);
-                if (gxy > b.d2) continue;
-                const bool shell = edge_i || (j == cy - r) || (j == cy + r);
-                const int row = (i * g.dy + j) * g.dz;
-                if (shell) {
-                    for (int k = k0; k <= k1; k++) {
-                        if (gxy + axis_gap2(qz, oz + k * h, oz + (k + 1) * h, margin) > b.d2) continue;
-                        scan_cell(g, row + k, qx, qy, qz, b);
-                    }
-                } else {
-                    if (cz - r >= 0 && !(gxy + axis_gap2(qz, oz + (cz - r) * h, oz + (cz - r + 1) * h, margin) > b.d2))
-                        scan_cell(g, row + cz - r, qx, qy, qz, b);
-                    if (cz + r < g.dz && !(gxy + axis_gap2(qz, oz + (cz + r) * h, oz + (cz + r + 1) * h, margin) > b.d2))
-                        scan_cell(g, row + cz + r, qx, qy, qz, b);
-                }
+    scan_cell(g, (cx * g.dy + cy) * g.dz + cz, qx, qy, qz, b);
+    const int i0 = max(cx - 1, 0), i1 = min(cx + 1, g.dx - 1);
+    const int j0 = max(cy - 1, 0), j1 = min(cy + 1, g.dy - 1);
+    const int k0 = max(cz - 1, 0), k1 = min(cz + 1, g.dz - 1);
+    for (int i = i0; i <= i1; i++) {
+        const double gx = axis_gap2(qx, ox + i * h, ox + (i + 1) * h, margin);
+        if (gx > b.d2) continue;
+        for (int j = j0; j <= j1; j++) {
+            const double gxy = gx + axis_gap2(qy, oy + j * h, oy + (j + 1) * h, margin);
+            if (gxy > b.d2) continue;
+            const int row = (i * g.dy + j) * g.dz;
+            for (int k = k0; k <= k1; k++) {
+                if (i == cx && j == cy && k == cz) continue;
+                if (gxy + axis_gap2(qz, oz + k * h, oz + (k + 1) * h, margin) > b.d2) continue;
+                scan_cell(g, row + k, qx, qy, qz, b);
             }
+        }
+    }
+    // Everything outside the 3x3x3 block lies beyond one of its six faces (where the grid continues).
+    double outside = INFINITY;
+    if (cx + 2 <= g.dx - 1) { const double t = fmax(ox + (cx + 2) * h - qx - margin, 0.0); outside = fmin(outside, t * t); }
+    if (cx - 2 >= 0)        { const double t = fmax(qx - (ox + (cx - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
+    if (cy + 2 <= g.dy - 1) { const double t = fmax(oy + (cy + 2) * h - qy - margin, 0.0); outside = fmin(outside, t * t); }
+    if (cy - 2 >= 0)        { const double t = fmax(qy - (oy + (cy - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
+    if (cz + 2 <= g.dz - 1) { const double t = fmax(oz + (cz + 2) * h - qz - margin, 0.0); outside = fmin(outside, t * t); }
+    if (cz - 2 >= 0)        { const double t = fmax(qz - (oz + (cz - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
+    if (outside > b.d2) return b;
+
+    // Pyramid walk. state[l] = coordinates of the node at level l being expanded (3 x 9 bits) | number
+    // of its children already handled (4 bits, at bit 27). Level nlev is a virtual root over the (at most
+    // 2 x 2 x 2) cells of the top level.
+    const int top = g.nlev - 1;
+    if (top == 0) return b;   // a grid of at most 2x2x2 cells was covered by the block above
+    int l = g.nlev;
+    state[l * sstride] = 0;
+    const unsigned order = 0x76534210u;   // children by number of flipped axes: 0,1,2,4,3,5,6,7
+    while (l <= g.nlev) {
+        const unsigned w = state[l * sstride];
+        const int t = (int)(w >> 27);
+        if (t == 8) { l++; continue; }
+        state[l * sstride] = w + (1u << 27);
+        const int ni = (int)((w >> 18) & 511), nj = (int)((w >> 9) & 511), nk = (int)(w & 511);
+        const int cl = l - 1;
+        const double cside = h * (double)(1 << cl);
+        const int near = (qx >= ox + (2 * ni + 1) * cside ? 4 : 0) | (qy >= oy + (2 * nj + 1) * cside ? 2 : 0) |
+                         (qz >= oz + (2 * nk + 1) * cside ? 1 : 0);
+        const int oct = near ^ (int)((order >> (4 * t)) & 7);
+        const int ci = 2 * ni + (oct >> 2), cj = 2 * nj + ((oct >> 1) & 1), ck = 2 * nk + (oct & 1);
+        const int cdx = lev_dim(g.dx, cl), cdy = lev_dim(g.dy, cl), cdz = lev_dim(g.dz, cl);
+        if (ci >= cdx || cj >= cdy || ck >= cdz) continue;
+        const size_t cidx = ((size_t)ci * cdy + cj) * cdz + ck;
+        if (cl == 0) {
+            const int2 r = g.range[cidx];
+            if (r.y <= r.x) continue;
+            if (box_lb2(qx, qy, qz, ox, oy, oz, cside, ci, cj, ck, margin) > b.d2) continue;
+            scan_cell(g, (int)cidx, qx, qy, qz, b);
+        } else {
+            if (!g.flags[loff[cl] + cidx]) continue;
+            if (box_lb2(qx, qy, qz, ox, oy, oz, cside, ci, cj, ck, margin) > b.d2) continue;
+            l = cl;
+            state[l * sstride] = ((unsigned)ci << 18) | ((unsigned)cj << 9) | (unsigned)ck;
         }
     }
     return b;
 }
 
 __global__ __launch_bounds__(256) void k_nn(GridView g, const double* __restrict__ q, size_t n, int* __restrict__ idx, double* __restrict__ d2) {
+    __shared__ unsigned stk[NN_LEVELS * 256];
+    __shared__ unsigned s_loff[MAXLEV];
+    if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
+    __syncthreads();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Best b = nn_search(g, q[3 * i], q[3 * i + 1], q[3 * i + 2]);
+    const Best b = nn_search(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], stk + threadIdx.x, 256, s_loff);
     if (idx) idx[i] = b.idx;
     if (d2) d2[i] = b.d2;
 }
 
 __global__ __launch_bounds__(256) void k_nn_distance(GridView g, const float* __restrict__ q, size_t n, float* __restrict__ out) {
+    __shared__ unsigned stk[NN_LEVELS * 256];
+    __shared__ unsigned s_loff[MAXLEV];
+    if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
+    __syncthreads();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Best b = nn_search(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2]);
+    const Best b = nn_search(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2], stk + threadIdx.x, 256, s_loff);
     out[i] = (float)__dsqrt_rn(b.d2);
 }
 
@@ -153,6 +224,10 @@ struct Mat34 { double m[12]; };
 __global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __restrict__ src, size_t n, Mat34 T,
                                                   const float* __restrict__ tgt_xyz, double* __restrict__ partials,
                                                   int* __restrict__ idx_out) {
+    __shared__ unsigned stk[NN_LEVELS * 256];
+    __shared__ unsigned s_loff[MAXLEV];
+    if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
+    __syncthreads();
     double acc[ICPX_NSUMS];
 #pragma unroll
     for (int k = 0; k < ICPX_NSUMS; k++) acc[k] = 0.0;
@@ -168,7 +243,7 @@ __global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __re
             a += T.m[4 * r + 3];
             p[r] = a;
         }
-        const Best b = nn_search(g, p[0], p[1], p[2]);
+        const Best b = nn_search(g, p[0], p[1], p[2], stk + threadIdx.x, 256, s_loff);
         if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
         const double q0 = (double)tgt_xyz[3 * (size_t)b.idx], q1 = (double)tgt_xyz[3 * (size_t)b.idx + 1], q2 = (double)tgt_xyz[3 * (size_t)b.idx + 2];
         acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
@@ -213,6 +288,9 @@ GridView view_of(const icpx_ctx* ctx) {
     g.h = ctx->gh; g.inv = ctx->ginv;
     g.range = ctx->cell_range.as<int2>();
     g.pts = ctx->sorted_pts.as<float4>();
+    g.flags = ctx->pyr_flags.as<unsigned char>();
+    g.loff = ctx->pyr_tab.as<unsigned>();
+    g.nlev = ctx->pyr_nlev;
     return g;
 }
 
@@ -271,6 +349,39 @@ int icpx_grid_build(icpx_ctx* ctx) {
     hipLaunchKernelGGL(k_gather_pts, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scratch_q.as<float4>(), ctx->sort_vals_b.as<unsigned>(), n,
                        ctx->sorted_pts.as<float4>());
     ICPX_TRY(icpx_launch_check(ctx, "k_gather_pts"));
+    // occupancy pyramid over the cells
+    {
+        int d[3] = {ctx->gdim[0], ctx->gdim[1], ctx->gdim[2]};
+        int nlev = 1;
+        unsigned off = 0;
+        ctx->pyr_dim[0][0] = d[0]; ctx->pyr_dim[0][1] = d[1]; ctx->pyr_dim[0][2] = d[2]; ctx->pyr_off[0] = 0;
+        while ((d[0] > 2 || d[1] > 2 || d[2] > 2) && nlev < MAXLEV) {
+            for (int c = 0; c < 3; c++) d[c] = (d[c] + 1) / 2;
+            ctx->pyr_dim[nlev][0] = d[0]; ctx->pyr_dim[nlev][1] = d[1]; ctx->pyr_dim[nlev][2] = d[2];
+            ctx->pyr_off[nlev] = off;
+            off += (unsigned)d[0] * d[1] * d[2];
+            nlev++;
+        }
+        for (int l = nlev; l < MAXLEV; l++) { ctx->pyr_dim[l][0] = ctx->pyr_dim[l][1] = ctx->pyr_dim[l][2] = 0; ctx->pyr_off[l] = 0; }
+        ctx->pyr_nlev = nlev;
+        ICPX_TRY(icpx_reserve(ctx, ctx->pyr_tab, MAXLEV * sizeof(unsigned)));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->pyr_tab.p, ctx->pyr_off, MAXLEV * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+        ICPX_TRY(icpx_reserve(ctx, ctx->pyr_flags, off ? off : 1));
+        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->pyr_flags.p, 0, off ? off : 1, ctx->stream));
+        unsigned char* fl = ctx->pyr_flags.as<unsigned char>();
+        for (int l = 1; l < nlev; l++) {
+            const int* lo = ctx->pyr_dim[l - 1]; const int* up = ctx->pyr_dim[l];
+            const size_t cells = (size_t)lo[0] * lo[1] * lo[2];
+            const unsigned nb = (unsigned)((cells + 255) / 256);
+            if (l == 1)
+                hipLaunchKernelGGL(k_pyr_from_cells, dim3(nb), dim3(256), 0, ctx->stream, ctx->cell_range.as<int2>(), lo[0], lo[1], lo[2],
+                                   fl + ctx->pyr_off[1], up[0], up[1], up[2]);
+            else
+                hipLaunchKernelGGL(k_pyr_from_flags, dim3(nb), dim3(256), 0, ctx->stream, fl + ctx->pyr_off[l - 1], lo[0], lo[1], lo[2],
+                                   fl + ctx->pyr_off[l], up[0], up[1], up[2]);
+        }
+        ICPX_TRY(icpx_launch_check(ctx, "pyramid kernels"));
+    }
     ctx->grid_ready = true;
     return ICPX_OK;
 }
