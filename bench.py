@@ -58,6 +58,24 @@ def rigid(axis, deg, t):
     return T
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest rocprofv3 counter summary under profiles/
+    (FETCH_SIZE + WRITE_SIZE, KiB, collected in separate --pmc passes by tools/prof_round.sh); None when
+    no summary is present. Offline evidence, not measured by this run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_edt_pmc.json")))
+    if not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))
+        for name, c in data.items():
+            if isinstance(c, dict) and name.startswith(kernel) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +84,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the NN / ICP / lookup extras")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--nn-points", type=int, default=1_000_000)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo for CPU-side rehearsal)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -75,9 +95,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_device:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -90,7 +115,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -120,7 +145,7 @@ def main():
     alg_bytes = 8.0 * voxels                       # one int32 read + one int32 write per voxel
     achieved = alg_bytes / (per_stage[dom] * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k_edt_pass_x", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic("k_edt_pass_x"),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_stage[dom],
                 "whole_build": {"algorithmic_bytes": 24.0 * voxels, "GB/s": 24.0 * voxels / (sum(per_stage.values()) * 1e-3) / 1e9,
                                 "frac": 24.0 * voxels / (sum(per_stage.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -156,9 +181,13 @@ def main():
 
         def icp_iter(T):
             ctx2.icp_step_async(T, sums)
-            if world > 1:
-                dist.all_reduce(sums)
-            s = sums.cpu().numpy()
+            if world > 1 and args.backend == "nccl":
+                dist.all_reduce(sums)          # RCCL, same stream as the kernel: no host round trip
+                s = sums.cpu().numpy()
+            elif world > 1:
+                hs = sums.cpu(); dist.all_reduce(hs); s = hs.numpy()
+            else:
+                s = sums.cpu().numpy()
             from icp_amd.host import kabsch_from_sums
             return kabsch_from_sums(s, n) @ T
 
