@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the NN / ICP / lookup extras")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--nn-points", type=int, default=1_000_000)
+    ap.add_argument("--no-goicp", action="store_true", help="skip the Go-ICP bunny-270 extra")
+    ap.add_argument("--goicp-width", type=int, default=8, help="translation parents popped per inner search and step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo for CPU-side rehearsal)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -202,6 +204,31 @@ def main():
         extra["icp_1m_rot_err_deg"] = float(np.rad2deg(np.arccos(np.clip((np.trace(T[:3, :3] @ Tm[:3, :3]) - 1) / 2, -1, 1))))
         extra["nn_roofline_frac"] = (36.0 * n + 12.0 * n * world) * iters / el / 1e9 / (HBM_PEAK_GBS * world)
         ctx2.close()
+
+        # Go-ICP on the reference's bunny pair (model bunny000 = bun315/bun000, data bun315/bun270), both
+        # clouds normalised isotropically into [-1,1]^3, DT 300^3, mse 1e-3; every bound batch is split
+        # over the ranks and combined by one sum all-reduce.
+        if not args.no_goicp:
+            from icp_amd.host import GoIcp, normalize_goicp
+            gm, gd, _ = normalize_goicp(load_scan("bunny000"), load_scan("bun270"))
+
+            def allreduce_host(a):
+                if args.backend == "nccl":
+                    t = torch.from_numpy(a).to(dev); dist.all_reduce(t); a[:] = t.cpu().numpy()
+                else:
+                    t = torch.from_numpy(a); dist.all_reduce(t)
+
+            go = GoIcp(gm, gd, mse=1e-3, dt_div=DIV, device=local, allreduce=allreduce_host, rank=rank, world=world)
+            go.options(batched=True, frontier_width=args.goicp_width)
+            barrier(); t0 = time.perf_counter()
+            gr = go.registration()
+            barrier()
+            el = max_over_ranks(time.perf_counter() - t0)
+            extra["goicp_bunny270"] = {"time_to_optimum_s": el, "optimal_sse": float(gr["optError"]), "lower_bound": float(gr["lb"]),
+                                       "epsilon": float(gr["sseThresh"]), "initial_sse": float(gr["initError"]), "icp_sse": float(gr["icpError"]),
+                                       "rotation_cubes": gr["rot_pops"], "bound_evaluations": gr["inner_evals"], "launches": gr["launches"],
+                                       "points": int(gd.shape[0]), "frontier_width": args.goicp_width}
+            del go
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -2,6 +2,7 @@
 // through include/icpx.h; what stays here is what the reference also does serially on the host:
 // 3x3 SVD, 4x4 algebra, priority queues and the branch-and-bound decisions.
 #include "icpx_host.hpp"
+#include "icpx_io.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -653,6 +654,25 @@ void icpxh_kabsch(const double* H9, double* R9) {
     std::memcpy(H.m, H9, sizeof H.m);
     const Matrix3d R = kabsch_rotation(H);
     std::memcpy(R9, R.m, sizeof R.m);
+}
+
+// ---- cloud input
+// Reads a PLY file; returns the number of valid vertices (or -1) and copies up to `cap` of them to xyz_out.
+long icpxh_load_ply(const char* path, float* xyz_out, long cap) {
+    PointCloudT c;
+    std::string err;
+    const long n = loadFile(path, c, &err);
+    if (n < 0) { g_err = err; return -1; }
+    for (long i = 0; i < n && i < cap; i++) { xyz_out[3 * i] = c.points[i].x; xyz_out[3 * i + 1] = c.points[i].y; xyz_out[3 * i + 2] = c.points[i].z; }
+    return n;
+}
+// In-place Go-ICP normalisation of two packed xyz arrays; returns the scale.
+double icpxh_normalize_goicp(float* model, size_t nm, float* data, size_t nd) {
+    PointCloudTPtr m = make_cloud(model, nm), d = make_cloud(data, nd);
+    const double s = normalize_goicp(*m, *d);
+    for (size_t i = 0; i < nm; i++) { model[3 * i] = m->points[i].x; model[3 * i + 1] = m->points[i].y; model[3 * i + 2] = m->points[i].z; }
+    for (size_t i = 0; i < nd; i++) { data[3 * i] = d->points[i].x; data[3 * i + 1] = d->points[i].y; data[3 * i + 2] = d->points[i].z; }
+    return s;
 }
 
 // ---- KDTree

@@ -36,6 +36,8 @@ def _lib():
         lib.icpxh_goicp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
         lib.icpxh_goicp_registration.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.icpxh_goicp_inner.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        lib.icpxh_load_ply.argtypes = [C.c_char_p, C.c_void_p, C.c_long]; lib.icpxh_load_ply.restype = C.c_long
+        lib.icpxh_normalize_goicp.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]; lib.icpxh_normalize_goicp.restype = C.c_double
         lib.icpxh_svd3.argtypes = [C.c_void_p] * 4
         lib.icpxh_kabsch.argtypes = [C.c_void_p] * 2
         _configured = True
@@ -59,6 +61,24 @@ def _new(ptr):
 
 def _f32(a):
     return np.ascontiguousarray(a, np.float32)
+
+
+def load_ply(path):
+    """Vertex positions of a PLY file (ascii or binary little endian), non-finite vertices dropped:
+    the C++ loadFile of csrc/host/icpx_io.cpp, which stands in for src/main.cpp:35-51."""
+    n = _lib().icpxh_load_ply(path.encode(), None, 0)
+    if n < 0:
+        raise IcpxError(-1, _lib().icpxh_last_error().decode())
+    out = np.empty((n, 3), np.float32)
+    _lib().icpxh_load_ply(path.encode(), _vp(out), n)
+    return out
+
+
+def normalize_goicp(model, data):
+    """(model', data', scale): each cloud about its own centroid, one scale into [-1, 1]^3."""
+    m, d = _f32(model).copy(), _f32(data).copy()
+    s = _lib().icpxh_normalize_goicp(_vp(m), m.shape[0], _vp(d), d.shape[0])
+    return m, d, s
 
 
 def svd3(A):

@@ -90,6 +90,49 @@ def test_kabsch_from_sums_recovers_a_rigid_motion():
     assert np.abs(host.kabsch_from_sums(s, 1000) - T).max() < 1e-12
 
 
+def _write_ply(path, xyz, binary=True, nan_rows=()):
+    xyz = np.array(xyz, np.float32)
+    for r in nan_rows:
+        xyz[r, 1] = np.nan
+    n = xyz.shape[0]
+    hdr = ("ply\nformat %s 1.0\ncomment test\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+           "property float nx\nproperty float ny\nproperty float nz\nproperty int flags\nelement face 0\n"
+           "property list uchar int vertex_indices\nend_header\n") % ("binary_little_endian" if binary else "ascii", n)
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        if binary:
+            rec = np.zeros(n, dtype=[("p", "<f4", 3), ("n", "<f4", 3), ("flags", "<i4")])
+            rec["p"] = xyz
+            f.write(rec.tobytes())
+        else:
+            for p in xyz:
+                f.write(("%r %r %r 0 0 1 0\n" % (float(p[0]), float(p[1]), float(p[2]))).encode())
+
+
+def test_ply_reader_and_normalisation(tmp_path, bunny045):
+    """loadFile of the host library (PLY vertex reader + NaN filter, src/main.cpp:35-51) on the 28-byte
+    vertex layout of the reference's scans, binary and ascii, and the Go-ICP normalisation."""
+    from icp_amd import host, IcpxError
+    pts = bunny045[:5000]
+    b, a = str(tmp_path / "b.ply"), str(tmp_path / "a.ply")
+    _write_ply(b, pts, binary=True, nan_rows=(3, 77))
+    _write_ply(a, pts[:200], binary=False)
+    got = host.load_ply(b)
+    keep = np.ones(len(pts), bool); keep[[3, 77]] = False
+    assert np.array_equal(got, pts[keep])
+    assert np.array_equal(host.load_ply(a), pts[:200])
+    with pytest.raises(IcpxError):
+        host.load_ply(str(tmp_path / "missing.ply"))
+    (tmp_path / "bad.ply").write_text("not a ply\n")
+    with pytest.raises(IcpxError):
+        host.load_ply(str(tmp_path / "bad.ply"))
+    m, d, s = host.normalize_goicp(pts, pts[::3] * 2.0 + 1.0)
+    assert abs(m.mean(0)).max() < 1e-6 and abs(d.mean(0)).max() < 1e-6
+    assert abs(max(np.abs(m).max(), np.abs(d).max()) - 1.0) < 1e-6
+    ref = (pts.astype(np.float64) - pts.astype(np.float64).mean(0)) * s
+    assert np.abs(m - ref).max() < 1e-6
+
+
 _WORKER = r'''
 import os, sys
 import numpy as np

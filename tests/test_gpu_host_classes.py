@@ -132,3 +132,21 @@ def test_goicp_bnb_small(oracle, bunny000, bun270):
     for batched in (False, True):
         got = GoIcp(model, data, mse=1e-2, dt_div=100).options(batched=batched, parity_sums=not batched).registration()
         assert abs(float(got["optError"]) - float(ref["optError"])) <= 1e-6 * float(ref["optError"]), (batched, got, ref)
+
+
+def test_command_line_driver(tmp_path, bunny000, bunny045):
+    """examples/icpx_main.cpp (argument order of src/main.cpp:247-301) on PLY files written from the fixtures."""
+    import os, subprocess
+    from conftest import ROOT
+    from test_abi_and_host_cpu import _write_ply
+    exe = os.path.join(ROOT, "icp_amd", "icpx_main")
+    assert os.path.exists(exe), "icp_amd/icpx_main is not built"
+    s, t = str(tmp_path / "s.ply"), str(tmp_path / "t.ply")
+    _write_ply(s, bunny000); _write_ply(t, bunny045)
+    out = subprocess.run([exe, s, t, "30", "0.001", "icp"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "source 40256 points, target 40097 points" in out.stdout
+    row0 = [float(v) for v in out.stdout.split("transMat:")[1].split("\n")[1].split()]
+    assert np.abs(np.array(row0) - [0.8447934139625265, 0.026791961891060055, -0.53442144278048831, 0.035047392296106809]).max() < 1e-8
+    out = subprocess.run([exe, s, t, "30", "0.001", "ldt"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "occupied 17459" in out.stdout, out.stdout + out.stderr
