@@ -55,7 +55,11 @@ class Context:
         return self._h
 
     def set_stream(self, stream_ptr):
+        """stream_ptr: a hipStream_t as an integer (torch.cuda.current_stream().cuda_stream); 0 is the default stream."""
         self._ck(self._lib.icpx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def reset_stream(self):
+        self._ck(self._lib.icpx_reset_stream(self._h))
 
     def sync(self):
         self._ck(self._lib.icpx_sync(self._h))

@@ -96,7 +96,15 @@ extern "C" int icpx_set_stream(icpx_ctx* ctx, void* hip_stream) {
     if (!ctx) return ICPX_EINVAL;
     ICPX_TRY(icpx_bind(ctx));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;   // NULL = the default stream
+    return ICPX_OK;
+}
+
+extern "C" int icpx_reset_stream(icpx_ctx* ctx) {
+    if (!ctx) return ICPX_EINVAL;
+    ICPX_TRY(icpx_bind(ctx));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
     return ICPX_OK;
 }
 

@@ -32,6 +32,7 @@ ICPX_SYMBOLS = {
     "icpx_destroy": (None, [C.c_void_p]),
     "icpx_last_error": (C.c_char_p, [C.c_void_p]),
     "icpx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "icpx_reset_stream": (C.c_int, [C.c_void_p]),
     "icpx_sync": (C.c_int, [C.c_void_p]),
     "icpx_device": (C.c_int, [C.c_void_p]),
     "icpx_set_target": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),

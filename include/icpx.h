@@ -52,9 +52,12 @@ void icpx_destroy(icpx_ctx* ctx);
 /* Text of the most recent error on this context (or of the last failed icpx_create when ctx is
  * NULL). Never NULL. */
 const char* icpx_last_error(const icpx_ctx* ctx);
-/* Use an existing hipStream_t (passed as void*) for all work of this context; NULL restores the
- * context's own stream. */
+/* Use an existing hipStream_t (passed as void*) for all work of this context; NULL means HIP's default
+ * (null) stream, which is what torch.cuda.current_stream() is unless the caller switched streams.
+ * icpx_reset_stream goes back to the stream the context created for itself. Both wait for the work
+ * already enqueued on the previous stream. */
 int icpx_set_stream(icpx_ctx* ctx, void* hip_stream);
+int icpx_reset_stream(icpx_ctx* ctx);
 int icpx_sync(icpx_ctx* ctx);
 int icpx_device(const icpx_ctx* ctx);
 

@@ -150,3 +150,22 @@ def test_command_line_driver(tmp_path, bunny000, bunny045):
     assert np.abs(np.array(row0) - [0.8447934139625265, 0.026791961891060055, -0.53442144278048831, 0.035047392296106809]).max() < 1e-8
     out = subprocess.run([exe, s, t, "30", "0.001", "ldt"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "occupied 17459" in out.stdout, out.stdout + out.stderr
+
+
+def test_goicp_bunny270_against_oracle_golden(bunny000, bun270):
+    """Go-ICP on the reference's bunny pair (every 8th data point, DT 300^3, mse 1e-3): the optimum found by
+    the batched GPU search equals the one the CPU oracle's serial best-first search certified
+    (tests/golden/goicp_bun270_stride8.json, made by tools/make_goicp_golden.py), within 1e-6 relative."""
+    import json, os
+    from conftest import GOLDEN
+    from icp_amd.host import GoIcp, normalize_goicp
+    gold = json.load(open(os.path.join(GOLDEN, "goicp_bun270_stride8.json")))
+    m, d, _ = normalize_goicp(bunny000, bun270)
+    d = np.ascontiguousarray(d[::8])
+    for width in (1, 8):
+        r = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=width).registration()
+        assert abs(float(r["optError"]) - gold["optError"]) <= 1e-6 * gold["optError"]
+        assert np.abs(r["optMat"] - np.array(gold["optMat"])).max() < 1e-5
+        assert float(r["initError"]) == gold["initError"]
+        assert abs(float(r["icpError"]) - gold["icpError"]) <= 1e-6 * gold["icpError"]
+        assert float(r["optError"]) - r["lb"] < r["sseThresh"]          # certificate

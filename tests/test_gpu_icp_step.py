@@ -24,3 +24,23 @@ def test_icp_step_sums_and_idx(gpu_ctx, oracle, bunny000, bunny045):
         ref, ridx = _sums_ref(oracle, bunny000, bunny045, T)
         assert np.array_equal(idx, ridx)
         np.testing.assert_allclose(sums, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_icp_step_async_on_torch_stream(gpu_ctx, oracle, bunny000, bunny045):
+    """The enqueue-only entry point on torch's current stream (the default stream and a side stream):
+    the device-resident sums are ordered with torch work on that stream."""
+    import torch
+    gpu_ctx.set_target(bunny045)
+    gpu_ctx.set_source(bunny000)
+    T = rigid([1, 0.5, -0.3], 5.0, [0.002, -0.001, 0.003])
+    ref = gpu_ctx.icp_step(T)
+    try:
+        for stream in (torch.cuda.current_stream(), torch.cuda.Stream()):
+            with torch.cuda.stream(stream):
+                gpu_ctx.set_stream(stream.cuda_stream)
+                sums = torch.zeros(16, dtype=torch.float64, device="cuda")
+                gpu_ctx.icp_step_async(T, sums)
+                doubled = (sums * 2).cpu().numpy()          # torch op queued behind the kernels on the same stream
+            assert np.array_equal(doubled, 2 * ref)
+    finally:
+        gpu_ctx.reset_stream()
