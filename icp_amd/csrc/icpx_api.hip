@@ -67,9 +67,16 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
     ctx->stream = ctx->own_stream;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
-    // Tuning knobs (LDS stack levels per lane of the two EDT envelope passes).
-    if (const char* v = getenv("ICPX_EDT_CAP_ZY")) { int c = atoi(v); if (c >= 1 && c <= 104) ctx->edt_cap_zy = c; }
-    if (const char* v = getenv("ICPX_EDT_CAP_X")) { int c = atoi(v); if (c >= 1 && c <= 85) ctx->edt_cap_x = c; }
+    // Tuning knobs of the EDT envelope passes: site groups per row block, LDS stack levels per lane and
+    // group (a workgroup may use 64 KiB of LDS).
+    // ICPX_EDT_ZY / ICPX_EDT_X = "groups,levels,chunks"; accepted only if the workgroup's LDS stays within 64 KiB.
+    for (int k = 0; k < 2; k++) {
+        const char* v = getenv(k ? "ICPX_EDT_X" : "ICPX_EDT_ZY");
+        int g = 0, c = 0, n = 0;
+        if (v && sscanf(v, "%d,%d,%d", &g, &c, &n) == 3 && g >= 1 && g <= 4 && c >= 2 && n >= 0 && n <= 254 &&
+            g * 384 + 512 + g * c * 384 + n * 48 <= 65536)
+            (k ? ctx->edt_x : ctx->edt_zy) = EnvTune{g, c, n};
+    }
     *out = ctx;
     return ICPX_OK;
 }
@@ -81,7 +88,7 @@ extern "C" void icpx_destroy(icpx_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->tgt_xyz, &ctx->cell_range, &ctx->pyr_flags, &ctx->pyr_tab, &ctx->sorted_pts, &ctx->sort_keys_a, &ctx->sort_keys_b,
                       &ctx->sort_vals_a, &ctx->sort_vals_b, &ctx->sort_tmp, &ctx->src_pts, &ctx->partials, &ctx->sums,
                       &ctx->scratch_q, &ctx->scratch_idx, &ctx->scratch_d2, &ctx->scratch_f, &ctx->edt_bits,
-                      &ctx->edt_rowlist, &ctx->edt_rowcnt, &ctx->edt_planelist, &ctx->edt_counters, &ctx->edt_plane,
+                      &ctx->edt_rowlist, &ctx->edt_rowcnt, &ctx->edt_planelist, &ctx->edt_counters, &ctx->edt_spill, &ctx->edt_plane,
                       &ctx->edt_sq, &ctx->data_pts, &ctx->maxrot, &ctx->bnb_items, &ctx->bnb_partials, &ctx->bnb_out,
                       &ctx->bnb_mindis};
     for (DevBuf* b : bufs)

@@ -17,6 +17,8 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+struct EnvTune { int groups, cap, chunks; };
+
 struct icpx_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -56,14 +58,16 @@ struct icpx_ctx {
     int edt_words = 0;       // 64-bit words per (x,y) bit row
     float edt_min[3] = {0, 0, 0};
     float edt_cell = 0.f;
-    // LDS stack levels per lane. zy: 4 B per level; x: 5 B (div <= 511) or 6 B per level. Sized so that
-    // six one-wave workgroups fit the 160 KiB of a CU (6 x 64 lanes x 80 levels x 5 B = 150 KiB).
-    int edt_cap_zy = 96, edt_cap_x = 80;
+    // Envelope passes: site groups (= waves) per 64 rows, private LDS levels per lane and group, pool
+    // chunks per workgroup. 4 x 28 x 64 x 6 bytes + 40 chunks x 48 bytes + header = 47 KiB: three
+    // workgroups (12 waves) per CU; measured best on the 300^3 bunny grid among the shapes tried.
+    EnvTune edt_zy{4, 28, 40}, edt_x{4, 28, 40};
     DevBuf edt_bits;         // div*div*edt_words uint64 occupancy bits
     DevBuf edt_rowlist;      // [x][chunk][k] 16-byte records of the non-empty rows of every plane (see k_edt_census)
     DevBuf edt_rowcnt;       // div int
     DevBuf edt_planelist;    // int32 ascending non-empty planes, padded with the last one to a multiple of 16 plus 16
-    DevBuf edt_counters;     // uint64 x 4: {occupied voxels, dropped points, nplanes, unused}
+    DevBuf edt_counters;     // uint64 x 8: {occupied voxels, dropped points, nplanes, unused, overflow zy, overflow x, -, -}
+    DevBuf edt_spill;        // NULL until a build overflowed the LDS stacks: [level - cap][group][row] 8-byte entries
     DevBuf edt_plane;        // div^3 int32: in-plane squared distances (only non-empty planes written)
     DevBuf edt_sq;           // div^3 int32: squared EDT, [x][y][z]
 

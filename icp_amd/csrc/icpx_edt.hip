@@ -10,16 +10,12 @@
 //   census   per plane x: records of the rows y that hold any occupied voxel; list of non-empty planes
 //   pass zy  per plane x and 64-wide z chunk (one lane per z): distance along z from the bit row
 //            (:91-109), then the lower envelope along y (:123-157); rows without voxels never win the
-//            envelope, so only listed rows are scanned
+//            envelope, so only the plane's non-empty rows are scanned
 //   pass x   per y and z chunk: lower envelope along x over the non-empty planes, writes the final
 //            squared grid (:172-206 before the sqrt)
 // Memory traffic: the only full-size arrays are the in-plane distances (written for non-empty planes,
 // read once) and the output; the occupancy is 1 bit per voxel and stays in L2.
-//
-// Envelope stacks: one lane owns one grid row; its stack of (site, start, value) entries lives in LDS
-// for the first `cap` levels ([level][lane], conflict-free) and, beyond that, in the lane's own
-// not-yet-written output slots (slot `level` of the row), which the scan-back has not reached when it
-// reads them back (level <= start[level] <= current position).
+// How the envelope scans are organised: see "lower envelope of parabolas" below.
 #include "icpx_ctx.h"
 #include "icpx_edt_dev.h"
 
@@ -110,50 +106,270 @@ __global__ __launch_bounds__(64) void k_edt_planes(const int* __restrict__ rowcn
     if (lane == 0) counters[2] = (u64)cnt;
 }
 
-// floor(N / D) for 0 <= N < 2^23, 1 <= D < 2^12 via a float reciprocal and correction steps.
+// floor(N / D) for 0 <= N < 2^23, 1 <= D < 2^12, exact whenever the quotient is below 2^12 (the callers
+// only use quotients below div <= 1023; larger ones just have to stay >= div, and the estimate is off by
+// at most 2 there). One float reciprocal, one multiply, one correction step in each direction.
 __device__ __forceinline__ int floordiv_pos(int N, int D) {
     int k = (int)((float)N * __builtin_amdgcn_rcpf((float)D));
-    int r = N - k * D;
-    if (r < 0) { k--; r += D; }
-    if (r < 0) { k--; r += D; }
-    if (r >= D) { k++; r -= D; }
-    if (r >= D) k++;
+    const int r = N - k * D;
+    k += (r >= D) - (r < 0);
     return k;
 }
 
 __device__ __forceinline__ int bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
+// (a - b)^2 + c for |a - b| < 2^23 (one subtract and one 24-bit multiply-add)
+__device__ __forceinline__ int sqdist(int a, int b, int c) { return __mul24(a - b, a - b) + c; }
+
+// Waits for outstanding global loads only. Placed inside the rarely taken spill branches so that their
+// loads are retired before control rejoins the hot path; otherwise the join point gets a wait for every
+// outstanding global load, including the prefetches of the next sites.
+__device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// ---- lower envelope of parabolas: 64 grid rows per workgroup, G waves per row group ---------------------
+// Both passes compute out[p] = min over sites u of (p - u)^2 + val[u], p = 0 .. div-1, for one grid row per
+// lane (Meijster's scan, src/testLDT.cpp:123-157 / :172-206). A serial scan over all sites of a row is one
+// long dependent chain and a div^3 grid only has div^2 rows, too few waves to keep the SIMDs busy, so the
+// scan is split: wave g of a workgroup builds the envelope stack of the g-th part of the row's sites (the
+// same 64 rows in every wave), then, after a barrier, wave g evaluates the g-th part of the positions
+// against all G stacks and takes the minimum. The stacks are never merged.
+//
+// A stack entry is {site s, value v} in one dword (s << 22 | v; v < 2^22 because div <= 1023) and the first
+// position t the entry owns among the entries of its own stack in a halfword. Where the levels live:
+//   level < cap                 LDS, [group][level][lane] (conflict-free)
+//   cap <= level < cap + 32     LDS pool shared by the workgroup: chunks of 8 levels, handed out with an
+//                               atomic counter the first time a stack reaches them; the four chunk ids of
+//                               a stack are the bytes of one dword (0xff = none)
+//   beyond, or pool exhausted   global spill buffer [level - cap][group][row] of 8-byte entries, allocated
+//                               only after a build reported through the overflow counter that it is needed
+// Most stacks are a handful of levels deep and a few are several times deeper, so a small private part
+// plus the shared pool holds what a fixed split of the same LDS could not.
+constexpr int ENV_VB = 22;
+constexpr unsigned ENV_VMASK = (1u << ENV_VB) - 1;
+constexpr int ENV_CHUNK = 8;        // levels per pool chunk
+constexpr int ENV_MAXCH = 4;        // chunks per stack
+
+template <int G>
+struct Env {
+    char* lds;
+    int cap, nch, lane;
+    int off_w, off_t, off_pw, off_pt;   // byte offsets: words [G][cap][64] u32, starts [G][cap][64] u16, pool words, pool starts
+    uint2* sp;               // spill buffer or NULL
+    int sp_levels;           // levels the spill buffer holds
+    size_t sp_rows, sp_row;  // rows in the pass, this lane's row
+    u64* ovf;                // overflow counter word
+    bool active;             // lane owns a row (idle lanes shadow the last row and never store)
+
+    // LDS header: depths [G][64] u16, chunk tables [G][64] u32, pool counter
+    __device__ __forceinline__ unsigned short& depth(int g) const { return *reinterpret_cast<unsigned short*>(lds + (g * 64 + lane) * 2); }
+    __device__ __forceinline__ unsigned& table(int g) const { return *reinterpret_cast<unsigned*>(lds + G * 128 + (g * 64 + lane) * 4); }
+    __device__ __forceinline__ unsigned* counter() const { return reinterpret_cast<unsigned*>(lds + G * 384); }
+    // byte addresses of level 0 of group g for this lane
+    __device__ __forceinline__ int wbase(int g) const { return off_w + g * cap * 256 + lane * 4; }
+    __device__ __forceinline__ int tbase(int g) const { return off_t + g * cap * 128 + lane * 2; }
+    __device__ __forceinline__ unsigned& W(int wb, int level) const { return *reinterpret_cast<unsigned*>(lds + wb + (level << 8)); }
+    __device__ __forceinline__ unsigned short& T(int tb, int level) const { return *reinterpret_cast<unsigned short*>(lds + tb + (level << 7)); }
+    __device__ __forceinline__ size_t spslot(int g, int level) const { return ((size_t)(level - cap) * G + g) * sp_rows + sp_row; }
+
+    // Pool slot of an overflow level, -1 when the level is not in the pool.
+    __device__ __forceinline__ int pool_slot(unsigned tab, int level) const {
+        const int L = level - cap, ci = L >> 3;
+        if (ci >= ENV_MAXCH) return -1;
+        const unsigned id = (tab >> (8 * ci)) & 0xffu;
+        return id == 0xffu ? -1 : (int)id * ENV_CHUNK + (L & 7);
+    }
+    __device__ void load_high(int g, unsigned tab, int level, unsigned& w, int& t) const {
+        const int ps = pool_slot(tab, level);
+        if (ps >= 0) {
+            w = *reinterpret_cast<unsigned*>(lds + off_pw + ps * 4);
+            t = *reinterpret_cast<unsigned short*>(lds + off_pt + ps * 2);
+        } else {
+            uint2 v = make_uint2(0, 0);
+            if (sp && level - cap < sp_levels) { v = sp[spslot(g, level)]; wait_vmem(); }
+            w = v.x; t = (int)v.y;
+        }
+    }
+    __device__ __forceinline__ void load(int g, int wb, int tb, unsigned tab, int level, unsigned& w, int& t) const {
+        if (level < cap) { w = W(wb, level); t = T(tb, level); }
+        else load_high(g, tab, level, w, t);
+    }
+    __device__ void store_high(int g, unsigned& tab, int level, unsigned w, int t) const {
+        const int L = level - cap, ci = L >> 3;
+        if (ci < ENV_MAXCH && ((tab >> (8 * ci)) & 0xffu) == 0xffu) {
+            const unsigned id = atomicAdd(counter(), 1u);
+            if (id < (unsigned)nch) tab = (tab & ~(0xffu << (8 * ci))) | (id << (8 * ci));
+        }
+        const int ps = pool_slot(tab, level);
+        if (ps >= 0) {
+            *reinterpret_cast<unsigned*>(lds + off_pw + ps * 4) = w;
+            *reinterpret_cast<unsigned short*>(lds + off_pt + ps * 2) = (unsigned short)t;
+        } else if (sp && level - cap < sp_levels) { if (active) sp[spslot(g, level)] = make_uint2(w, (unsigned)t); }
+        else *ovf = 1;
+    }
+    __device__ __forceinline__ void store(int g, int wb, int tb, unsigned& tab, int level, unsigned w, int t) const {
+        if (level < cap) { W(wb, level) = w; T(tb, level) = (unsigned short)t; }
+        else store_high(g, tab, level, w, t);
+    }
+};
+
+// Scan state of one stack: the top entry unpacked, the entry below it packed.
+struct EnvTop {
+    int q;                  // index of the top entry, -1 = empty
+    int ts, tv, tt;         // top: site, value, start
+    unsigned tw;            // top, packed
+    unsigned bw; int bt;    // entry below the top (undefined when q < 1)
+    int wb, tb;             // LDS byte addresses of level 0 of this stack
+    unsigned tab;           // pool chunk ids of this stack
+};
+
+template <int G>
+__device__ __forceinline__ void env_init(const Env<G>& E, int g, EnvTop& e) {
+    e = EnvTop{-1, 0, 0, 0, 0u, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu};
+}
+
+// Adds site u (ascending) with value v to the stack of group g: pop while the new parabola is lower at
+// the start of the top entry, then enter it at the first position where it is lower than the top, if
+// that position is inside the row (src/testLDT.cpp:136-150). Reads below the bottom of a stack return
+// whatever precedes it in LDS and are never used.
+template <int G>
+__device__ __forceinline__ void env_add(const Env<G>& E, int g, EnvTop& e, int u, int v, int div) {
+    while (e.q >= 0 && sqdist(e.tt, e.ts, e.tv) > sqdist(e.tt, u, v)) {
+        e.tw = e.bw; e.ts = (int)(e.bw >> ENV_VB); e.tv = (int)(e.bw & ENV_VMASK); e.tt = e.bt;
+        e.q--;
+        E.load(g, e.wb, e.tb, e.tab, e.q - 1, e.bw, e.bt);
+    }
+    const int du = u - e.ts;
+    int w = 1 + floordiv_pos(__mul24(u + e.ts, du) + (v - e.tv), 2 * du);
+    if (e.q < 0) w = 0;
+    if (w < div) {
+        e.bw = e.tw; e.bt = e.tt;
+        e.tw = ((unsigned)u << ENV_VB) | (unsigned)v; e.ts = u; e.tv = v; e.tt = w;
+        e.q++;
+        E.store(g, e.wb, e.tb, e.tab, e.q, e.tw, w);
+    }
+}
+
+// Ends the scan of group g: publishes depth and chunk table (a group without sites gets one entry that
+// loses against every real one).
+template <int G>
+__device__ __forceinline__ void env_finish(const Env<G>& E, int g, EnvTop& e) {
+    if (e.q < 0) { e.q = 0; E.store(g, e.wb, e.tb, e.tab, 0, ENV_VMASK, 0); }
+    E.depth(g) = (unsigned short)e.q;
+    E.table(g) = e.tab;
+}
+
+// Evaluation cursor on one stack, walking towards position 0.
+struct EnvCur {
+    int lvl;                // level of the current entry
+    unsigned cw; int ct;    // current entry
+    int wb, tb;             // LDS byte addresses of level 0 of the stack
+    unsigned tab;
+};
+
+// Positions the cursor on the entry of group j that owns position p (largest level whose start is <= p).
+template <int G>
+__device__ __forceinline__ void env_seek(const Env<G>& E, int j, EnvCur& c, int p) {
+    c.wb = E.wbase(j); c.tb = E.tbase(j); c.tab = E.table(j);
+    int lo = 0, hi = E.depth(j);
+    while (lo < hi) {
+        const int m = (lo + hi + 1) >> 1;
+        unsigned w; int t;
+        E.load(j, c.wb, c.tb, c.tab, m, w, t);
+        if (t <= p) lo = m; else hi = m - 1;
+    }
+    c.lvl = lo;
+    E.load(j, c.wb, c.tb, c.tab, lo, c.cw, c.ct);
+}
+
+// Value of stack j's envelope at position p, then one level down if p was the first position of the
+// entry; the entry of the new level is read back every time, which keeps the step branch-free.
+// HIGH: some lane's cursor may still be above the private levels.
+template <int G, bool HIGH>
+__device__ __forceinline__ int env_eval(const Env<G>& E, int j, EnvCur& c, int p) {
+    const int d = (p & 0x3ff) - (int)(c.cw >> ENV_VB);      // |d| <= 1023: the product is a 24-bit multiply
+    const int v = d * d + (int)(c.cw & ENV_VMASK);
+    c.lvl -= p == c.ct ? 1 : 0;
+    if (HIGH) E.load(j, c.wb, c.tb, c.tab, c.lvl, c.cw, c.ct);
+    else { c.cw = E.W(c.wb, c.lvl); c.ct = E.T(c.tb, c.lvl); }
+    return v;
+}
+
+// Writes positions [plo, phi) of this lane's row: out[p * stride + lane_off] = min over the G stacks.
+template <int G>
+__device__ __forceinline__ void env_write(const Env<G>& E, int* __restrict__ out, size_t stride, unsigned lane_off, int plo, int phi) {
+    if (phi <= plo) return;
+    EnvCur cur[G];
+#pragma unroll
+    for (int j = 0; j < G; j++) env_seek(E, j, cur[j], phi - 1);
+    int p = phi - 1;
+    for (;;) {   // general steps while any cursor of the wave is above the private levels
+        bool high = false;
+#pragma unroll
+        for (int j = 0; j < G; j++) high |= cur[j].lvl >= E.cap;
+        if (p < plo || !__any(high)) break;
+        int v = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < G; j++) v = min(v, env_eval<G, true>(E, j, cur[j], p));
+        if (E.active) (out + (size_t)p * stride)[lane_off] = v;
+        p--;
+    }
+    for (; p >= plo; p--) {
+        int v = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < G; j++) v = min(v, env_eval<G, false>(E, j, cur[j], p));
+        if (E.active) (out + (size_t)p * stride)[lane_off] = v;
+    }
+}
+
+// LDS layout: header (depths, chunk tables, pool counter) padded so that reads two levels below level 0
+// of group 0 stay inside the allocation, then the private levels, then the pool.
+static inline int env_off_w(int G) { return G * 384 + 512; }
+static size_t env_lds_bytes(int G, int cap, int nch) { return (size_t)env_off_w(G) + (size_t)G * cap * 384 + (size_t)nch * ENV_CHUNK * 6; }
+
+template <int G>
+__device__ __forceinline__ Env<G> env_setup(unsigned* lds, int cap, int nch, int lane, uint2* sp, int div, size_t rows, size_t row,
+                                            u64* ovf, bool active) {
+    Env<G> E;
+    E.lds = reinterpret_cast<char*>(lds);
+    E.cap = cap; E.nch = nch; E.lane = lane;
+    E.off_w = G * 384 + 512;
+    E.off_t = E.off_w + G * cap * 256;
+    E.off_pw = E.off_t + G * cap * 128;
+    E.off_pt = E.off_pw + nch * ENV_CHUNK * 4;
+    E.sp = sp; E.sp_levels = max((div + G - 1) / G + 1 - cap, 1);   // the host sizes the buffer with the same rule
+    E.sp_rows = rows; E.sp_row = row; E.ovf = ovf; E.active = active;
+    if (threadIdx.x == 0) *E.counter() = 0;
+    __syncthreads();
+    return E;
+}
+
 // ---- pass zy ------------------------------------------------------------------------------------------
-// One wave = plane x, z chunk c; lane = z. The records of the plane's non-empty rows are fetched 64 at a
-// time (lane j holds record j, one coalesced 1 KiB load, the next block prefetched) and broadcast with
-// v_readlane as the scan reaches them, so the serial scan never waits on memory.
-// Stack entry: site (10 bits) | start (10 bits) | distance along z (10 bits).
-// `plane` and `spill_base` are the same array: results are stored through the first, spilled stack
-// entries are written and read through the second. Declaring them as unrelated pointers lets the
-// scan-back keep its result stores in flight; the only same-address pairs (a spilled entry and the
-// result that later overwrites its slot) are ordered by the data dependency on the popped entry.
-__global__ __launch_bounds__(64) void k_edt_pass_zy(const RowRec* __restrict__ recs, const int* __restrict__ rowcnt,
-                                                    int* __restrict__ plane, int* __restrict__ spill_base, int div, int W, int cap) {
-    extern __shared__ unsigned lds[];   // [cap][64]
+// Workgroup = plane x, 64 consecutive z; lane = z. Sites are the plane's non-empty rows y; their records
+// are fetched 64 at a time (lane j holds record j of the wave's site range, one coalesced load, the next
+// block prefetched) and broadcast with v_readlane as the scan reaches them. Value = (distance along z)^2.
+template <int G>
+__global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict__ recs, const int* __restrict__ rowcnt,
+                                                        int* __restrict__ plane, uint2* __restrict__ spill_buf, u64* __restrict__ counters,
+                                                        int div, int W, int cap, int nch) {
+    extern __shared__ unsigned lds[];
     const int x = blockIdx.x / W, c = blockIdx.x % W;
     const int cnt = rowcnt[x];
     if (cnt == 0) return;   // plane without voxels: never read by pass x
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool active = c * 64 + lane < div;
-    const int z = active ? c * 64 + lane : div - 1;      // idle lanes shadow the last valid z and never store
-    const int zl = z - c * 64;                            // bit position inside the chunk word
-    const size_t rowstride = (size_t)div;
-    int* __restrict__ out = plane + (size_t)x * div * div + z;         // out[y * div]
-    int* __restrict__ spill = spill_base + (size_t)x * div * div + z;  // spill[level * div]
-    const RowRec* rr = recs + ((size_t)x * W + c) * div;
+    const int z = active ? c * 64 + lane : div - 1;
+    const int zl = z & 63;
+    const Env<G> E = env_setup<G>(lds, cap, nch, lane, spill_buf, div, (size_t)div * div, (size_t)x * div + z, &counters[4], active);
 
-    int q = -1, ts = 0, tt = 0, tg = 0;   // cached top entry
-    const int4* rr4 = reinterpret_cast<const int4*>(rr);
-    int4 nxt = lane < cnt ? rr4[lane] : make_int4(0, 0, 0, 0);
-    for (int k0 = 0; k0 < cnt; k0 += 64) {
+    const int klo = cnt * g / G, khi = cnt * (g + 1) / G;
+    const int4* rr4 = reinterpret_cast<const int4*>(recs + ((size_t)x * W + c) * div);
+    EnvTop e;
+    env_init(E, g, e);
+    int4 nxt = klo + lane < khi ? rr4[klo + lane] : make_int4(0, 0, 0, 0);
+    for (int k0 = klo; k0 < khi; k0 += 64) {
         const int4 cur = nxt;
-        if (k0 + 64 + lane < cnt) nxt = rr4[k0 + 64 + lane];
-        const int m = min(64, cnt - k0);
+        if (k0 + 64 + lane < khi) nxt = rr4[k0 + 64 + lane];
+        const int m = min(64, khi - k0);
         for (int j = 0; j < m; j++) {
             const unsigned lo = (unsigned)bcast(cur.x, j), hi = (unsigned)bcast(cur.y, j);
             const unsigned ba = (unsigned)bcast(cur.z, j);
@@ -164,163 +380,59 @@ __global__ __launch_bounds__(64) void k_edt_pass_zy(const RowRec* __restrict__ r
             const u64 mu = own >> zl;
             const int down = md ? zl - (63 - __clzll(md)) : (below >= 0 ? z - below : BIGD);
             const int up = mu ? (__ffsll((long long)mu) - 1) : (above != 0xffff ? above - z : BIGD);
-            const int g = min(down, up);
-            const int Gu = g * g;
-
-            if (q >= 0) {
-                while (true) {
-                    const int a = (tt - ts) * (tt - ts) + tg * tg;
-                    const int b = (tt - u) * (tt - u) + Gu;
-                    if (a <= b) break;
-                    q--;
-                    if (q < 0) break;
-                    if (q < cap) { const unsigned e = lds[q * 64 + lane]; ts = e & 1023; tt = (e >> 10) & 1023; tg = e >> 20; }
-                    else { const unsigned e = (unsigned)spill[(size_t)q * rowstride]; ts = e & 1023; tt = (e >> 10) & 1023; tg = e >> 20; }
-                }
-            }
-            bool push = false;
-            int w = 0;
-            if (q < 0) { q = 0; push = true; }
-            else {
-                w = 1 + floordiv_pos(u * u - ts * ts + Gu - tg * tg, 2 * (u - ts));
-                if (w < div) { q++; push = true; }
-            }
-            if (push) {
-                ts = u; tt = w; tg = g;
-                const unsigned e = (unsigned)u | ((unsigned)w << 10) | ((unsigned)g << 20);
-                if (q < cap) lds[q * 64 + lane] = e;
-                else if (active) spill[(size_t)q * rowstride] = (int)e;
-            }
+            const int gd = min(down, up);
+            env_add(E, g, e, u, __mul24(gd, gd), div);
         }
     }
-    for (int y = div - 1; y >= 0; y--) {
-        const int v = (y - ts) * (y - ts) + tg * tg;
-        if (active) out[(size_t)y * rowstride] = v;
-        if ((y == tt) && q > 0) {
-            q--;
-            if (q < cap) { const unsigned e = lds[q * 64 + lane]; ts = e & 1023; tt = (e >> 10) & 1023; tg = e >> 20; }
-            else { const unsigned e = (unsigned)spill[(size_t)q * rowstride]; ts = e & 1023; tt = (e >> 10) & 1023; tg = e >> 20; }
-        }
-    }
+    env_finish(E, g, e);
+    __syncthreads();
+    env_write(E, plane + (size_t)x * div * div, (size_t)div, (unsigned)z, div * g / G, div * (g + 1) / G);
 }
 
 // ---- pass x ---------------------------------------------------------------------------------------------
-// One wave = row y, z chunk c; lane = z. Sites are the non-empty planes; their in-plane distances are
-// fetched PF planes ahead of the scan. A stack entry is {site, start, value}; value needs up to 22 bits,
-// so an entry takes 5 bytes for div <= 511 (9 + 9 + 20 bits + 2 spare: a dword plus a byte) and 6 bytes
-// otherwise (10 + 10 + 22: a dword plus a halfword), which lets six waves per CU keep 85 / 71 levels in
-// LDS. Deeper levels go to the lane's output slots as {site | start << 16} and re-read the value.
-// The top two entries are kept in registers, so a pop costs no LDS round trip unless pops follow at once.
-constexpr int EDT_PF = 16;
+// Workgroup = row y, 64 consecutive z; lane = z. Sites are the non-empty planes; wave g scans the g-th
+// part of the plane list, fetching the in-plane distances EDT_PF planes ahead (the list is padded, so
+// the group loads need no bounds checks; indices are wave-uniform scalar loads, values one coalesced load
+// per plane).
+constexpr int EDT_PF = 8;
 
-template <bool SMALL> struct XEntry;
-template <> struct XEntry<true> {     // div <= 511
-    typedef unsigned char hi_t;
-    static __device__ __forceinline__ void pack(int s, int t, int G, unsigned& lo, hi_t& hi) {
-        lo = (unsigned)G | ((unsigned)s << 20) | ((unsigned)(t & 7) << 29);
-        hi = (hi_t)(t >> 3);
-    }
-    static __device__ __forceinline__ void unpack(unsigned lo, unsigned hi, int& s, int& t, int& G) {
-        G = lo & 0xfffff; s = (lo >> 20) & 511; t = (int)(lo >> 29) | ((int)hi << 3);
-    }
-};
-template <> struct XEntry<false> {    // div <= 1023
-    typedef unsigned short hi_t;
-    static __device__ __forceinline__ void pack(int s, int t, int G, unsigned& lo, hi_t& hi) {
-        lo = (unsigned)G | ((unsigned)s << 22);
-        hi = (hi_t)t;
-    }
-    static __device__ __forceinline__ void unpack(unsigned lo, unsigned hi, int& s, int& t, int& G) {
-        G = lo & 0x3fffff; s = lo >> 22; t = (int)hi;
-    }
-};
-
-template <bool SMALL, int ABL = 0>
-__global__ __launch_bounds__(64) void k_edt_pass_x(const int* __restrict__ plane, const int* __restrict__ planelist,
-                                                   const u64* __restrict__ counters, int* __restrict__ sq, int* __restrict__ spill_base,
-                                                   int div, int nchunk, int cap) {
-    typedef XEntry<SMALL> E;
-    typedef typename E::hi_t hi_t;
-    extern __shared__ unsigned lds[];   // [cap][64] dwords, then [cap][64] hi_t
-    hi_t* lds_h = reinterpret_cast<hi_t*>(lds + cap * 64);
+template <int G>
+__global__ __launch_bounds__(64 * G) void k_edt_pass_x(const int* __restrict__ plane, const int* __restrict__ planelist,
+                                                       u64* __restrict__ counters, int* __restrict__ sq, uint2* __restrict__ spill_buf,
+                                                       int div, int nchunk, int cap, int nch) {
+    extern __shared__ unsigned lds[];
     const int y = blockIdx.x / nchunk, c = blockIdx.x % nchunk;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool active = c * 64 + lane < div;
     const int z = active ? c * 64 + lane : div - 1;
-    int np = (int)counters[2];
-    if (ABL == 3) np = min(np, 16);
+    const int np = (int)counters[2];
     const size_t xs = (size_t)div * div;                  // elements between consecutive x
-    const int* in = plane + (size_t)y * div + z;          // in[u * xs]
-    int* __restrict__ out = sq + (size_t)y * div + z;                  // out[x * xs]
-    int* __restrict__ spill = spill_base + (size_t)y * div + z;        // same array as `sq` (see pass zy)
+    const int rowoff = y * div + z;
+    const Env<G> E = env_setup<G>(lds, cap, nch, lane, spill_buf, div, xs, (size_t)rowoff, &counters[5], active);
 
-    // loads entry `lvl` of this lane's stack
-    auto fetch = [&](int lvl, int& s_, int& t_, int& G_) {
-        if (lvl < cap) E::unpack(lds[lvl * 64 + lane], lds_h[lvl * 64 + lane], s_, t_, G_);
-        else { const unsigned e = (unsigned)spill[(size_t)lvl * xs]; s_ = e & 0xffff; t_ = e >> 16; G_ = in[(size_t)s_ * xs]; }
-    };
-
-    int q = -1;                       // index of the top entry
-    int ts = 0, tt = 0, tG = 0;       // top entry
-    int bs = 0, bt = 0, bG = 0;       // entry below the top (valid when q >= 1)
-    // planelist is padded (see k_edt_planes), so the group loads below need no bounds checks; the
-    // indices are wave-uniform scalar loads, the values one coalesced 256-byte load per plane.
+    const int klo = np * g / G, khi = np * (g + 1) / G;
+    EnvTop e;
+    env_init(E, g, e);
     int Gn[EDT_PF], Un[EDT_PF];
 #pragma unroll
-    for (int j = 0; j < EDT_PF; j++) Un[j] = planelist[j];
+    for (int j = 0; j < EDT_PF; j++) Un[j] = planelist[klo + j];
 #pragma unroll
-    for (int j = 0; j < EDT_PF; j++) Gn[j] = in[(size_t)Un[j] * xs];
-    for (int k0 = 0; k0 < np; k0 += EDT_PF) {
+    for (int j = 0; j < EDT_PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
+    for (int k0 = klo; k0 < khi; k0 += EDT_PF) {
         int Gc[EDT_PF], Uc[EDT_PF];
 #pragma unroll
         for (int j = 0; j < EDT_PF; j++) { Gc[j] = Gn[j]; Uc[j] = Un[j]; }
 #pragma unroll
         for (int j = 0; j < EDT_PF; j++) Un[j] = planelist[k0 + EDT_PF + j];
 #pragma unroll
-        for (int j = 0; j < EDT_PF; j++) Gn[j] = in[(size_t)Un[j] * xs];
+        for (int j = 0; j < EDT_PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
 #pragma unroll
-        for (int j = 0; j < EDT_PF; j++) {
-            if (k0 + j < np) {
-                const int u = Uc[j], Gu = Gc[j];
-                while (q >= 0) {
-                    const int a = (tt - ts) * (tt - ts) + tG;
-                    const int b = (tt - u) * (tt - u) + Gu;
-                    if (a <= b) break;
-                    q--;                                   // pop: the entry below becomes the top
-                    ts = bs; tt = bt; tG = bG;
-                    if (q >= 1) fetch(q - 1, bs, bt, bG);
-                }
-                bool push = false;
-                int w = 0;
-                if (q < 0) { q = 0; push = true; }
-                else {
-                    w = 1 + floordiv_pos(u * u - ts * ts + Gu - tG, 2 * (u - ts));
-                    if (w < div) { q++; push = true; }
-                }
-                if (push) {
-                    bs = ts; bt = tt; bG = tG;
-                    ts = u; tt = w; tG = Gu;
-                    if (q < cap) {
-                        unsigned lo; hi_t hi;
-                        E::pack(u, w, Gu, lo, hi);
-                        lds[q * 64 + lane] = lo; lds_h[q * 64 + lane] = hi;
-                    } else if (active) spill[(size_t)q * xs] = (int)((unsigned)u | ((unsigned)w << 16));
-                }
-            }
-        }
+        for (int j = 0; j < EDT_PF; j++)
+            if (k0 + j < khi) env_add(E, g, e, Uc[j], Gc[j], div);
     }
-    int chk = 0;
-    for (int x = (ABL == 2 ? 0 : div - 1); x >= 0; x--) {
-        const int v = (x - ts) * (x - ts) + tG;
-        if (ABL == 1) chk += v;
-        else if (active) out[(size_t)x * xs] = v;
-        if ((x == tt) && q > 0) {
-            q--;
-            ts = bs; tt = bt; tG = bG;
-            if (q >= 1) fetch(q - 1, bs, bt, bG);
-        }
-    }
-    if (ABL == 1 && active) out[0] = chk;
+    env_finish(E, g, e);
+    __syncthreads();
+    env_write(E, sq, xs, (unsigned)rowoff, div * g / G, div * (g + 1) / G);
 }
 
 // ---- lookup (device function in icpx_edt_dev.h) ----
@@ -333,14 +445,28 @@ __global__ void k_edt_lookup(const int* __restrict__ sq, int div, float mnx, flo
 
 }  // namespace
 
+// Size of the spill buffer of the envelope passes at the current resolution: one 8-byte entry per row, site
+// group and level beyond the private ones (a group holds at most ceil(div / groups) sites).
+static size_t edt_spill_bytes(const icpx_ctx* ctx) {
+    size_t need = 0;
+    for (const EnvTune* t : {&ctx->edt_zy, &ctx->edt_x}) {
+        const int levels = std::max(((int)ctx->div + t->groups - 1) / t->groups + 1 - t->cap, 1);
+        need = std::max(need, (size_t)levels * t->groups * ctx->div * ctx->div * sizeof(uint2));
+    }
+    return need;
+}
+
 // ev: NULL, or ICPX_EDT_NSTAGES + 1 events recorded around the stages (clear, splat, census, pass zy, pass x).
 static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
     const int div = (int)ctx->div, W = ctx->edt_words;
     const int nchunk = (div + 63) / 64;
     hipStream_t s = ctx->stream;
+    // A spill buffer left from a build at a lower resolution is too small for this one: run without it
+    // (the build then reports the overflow, if any, and the buffer is grown).
+    uint2* spill = ctx->edt_spill.cap >= edt_spill_bytes(ctx) ? ctx->edt_spill.as<uint2>() : nullptr;
     if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[0], s));
     ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_bits.p, 0, (size_t)div * div * W * sizeof(u64), s));
-    ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_counters.p, 0, 4 * sizeof(u64), s));
+    ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_counters.p, 0, 8 * sizeof(u64), s));
     if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(k_edt_splat, dim3((unsigned)((ctx->nt + 255) / 256)), dim3(256), 0, s, ctx->tgt_xyz.as<float>(), ctx->nt,
                        ctx->edt_min[0], ctx->edt_min[1], ctx->edt_min[2], ctx->edt_cell, div, W, ctx->edt_bits.as<u64>(),
@@ -351,19 +477,21 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
     hipLaunchKernelGGL(k_edt_planes, dim3(1), dim3(64), 0, s, ctx->edt_rowcnt.as<int>(), div, (div + 15) / 16 * 16 + 16,
                        ctx->edt_planelist.as<int>(), ctx->edt_counters.as<u64>());
     if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[3], s));
-    hipLaunchKernelGGL(k_edt_pass_zy, dim3(div * nchunk), dim3(64), (size_t)ctx->edt_cap_zy * 64 * 4, s, ctx->edt_rowlist.as<RowRec>(),
-                       ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), ctx->edt_plane.as<int>(), div, W, ctx->edt_cap_zy);
+    {
+        const int G = ctx->edt_zy.groups, cap = ctx->edt_zy.cap, nch = ctx->edt_zy.chunks;
+        auto zy = G == 1 ? k_edt_pass_zy<1> : G == 2 ? k_edt_pass_zy<2> : G == 3 ? k_edt_pass_zy<3> : k_edt_pass_zy<4>;
+        hipLaunchKernelGGL(zy, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ctx->edt_rowlist.as<RowRec>(),
+                           ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, ctx->edt_counters.as<u64>(), div,
+                           W, cap, nch);
+    }
     if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[4], s));
-    static const int abl = getenv("ICPX_EDT_ABLATE") ? atoi(getenv("ICPX_EDT_ABLATE")) : 0;
-    auto kx = abl == 1 ? k_edt_pass_x<true, 1> : abl == 2 ? k_edt_pass_x<true, 2> : abl == 3 ? k_edt_pass_x<true, 3> : k_edt_pass_x<true, 0>;
-    if (div <= 511)
-        hipLaunchKernelGGL(kx, dim3(div * nchunk), dim3(64), (size_t)ctx->edt_cap_x * 64 * 5, s, ctx->edt_plane.as<int>(),
-                           ctx->edt_planelist.as<int>(), ctx->edt_counters.as<u64>(), ctx->edt_sq.as<int>(), ctx->edt_sq.as<int>(),
-                           div, nchunk, ctx->edt_cap_x);
-    else
-        hipLaunchKernelGGL(k_edt_pass_x<false>, dim3(div * nchunk), dim3(64), (size_t)std::min(ctx->edt_cap_x, 71) * 64 * 6, s,
-                           ctx->edt_plane.as<int>(), ctx->edt_planelist.as<int>(), ctx->edt_counters.as<u64>(),
-                           ctx->edt_sq.as<int>(), ctx->edt_sq.as<int>(), div, nchunk, std::min(ctx->edt_cap_x, 71));
+    {
+        const int G = ctx->edt_x.groups, cap = ctx->edt_x.cap, nch = ctx->edt_x.chunks;
+        auto px = G == 1 ? k_edt_pass_x<1> : G == 2 ? k_edt_pass_x<2> : G == 3 ? k_edt_pass_x<3> : k_edt_pass_x<4>;
+        hipLaunchKernelGGL(px, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ctx->edt_plane.as<int>(),
+                           ctx->edt_planelist.as<int>(), ctx->edt_counters.as<u64>(), ctx->edt_sq.as<int>(), spill, div,
+                           nchunk, cap, nch);
+    }
     if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[5], s));
     return icpx_launch_check(ctx, "EDT kernels");
 }
@@ -406,7 +534,7 @@ static int edt_prepare(icpx_ctx* ctx, uint32_t div) {
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_rowlist, (size_t)div * div * ctx->edt_words * 16));   // RowRec records
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_rowcnt, (size_t)div * sizeof(int)));
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_planelist, (size_t)((div + 15) / 16 * 16 + 16) * sizeof(int)));
-    ICPX_TRY(icpx_reserve(ctx, ctx->edt_counters, 4 * sizeof(u64)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_counters, 8 * sizeof(u64)));
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_plane, n3 * sizeof(int)));
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_sq, n3 * sizeof(int)));
     return ICPX_OK;
@@ -418,11 +546,18 @@ extern "C" int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[
     ICPX_TRY(edt_prepare(ctx, div));
     ctx->edt_min[0] = min3[0]; ctx->edt_min[1] = min3[1]; ctx->edt_min[2] = min3[2];
     ctx->edt_cell = cell_len;
-    ICPX_TRY(icpx_edt_run(ctx));
-    u64 counters[4];
-    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, ctx->edt_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
-    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (counters[0] == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "EDT build: no target point falls inside the grid");
+    for (int attempt = 0; attempt < 2; attempt++) {
+        ICPX_TRY(icpx_edt_run(ctx));
+        u64 counters[8];
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, ctx->edt_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
+        ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (counters[0] == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "EDT build: no target point falls inside the grid");
+        if (!counters[4] && !counters[5]) break;
+        // Some row's envelope did not fit the LDS levels and pool: give the passes a spill buffer and repeat
+        // the build.
+        if (attempt == 1) ICPX_FAIL(ctx, ICPX_EHIP, "EDT build: stack overflow persisted with a spill buffer");
+        ICPX_TRY(icpx_reserve(ctx, ctx->edt_spill, edt_spill_bytes(ctx)));
+    }
     ctx->edt_ready = true;
     return ICPX_OK;
 }

@@ -311,7 +311,7 @@ int icpx_grid_build(icpx_ctx* ctx) {
     const unsigned blocks = (unsigned)((n + 255) / 256);
     ICPX_TRY(icpx_sort_reserve(ctx, n));
     ICPX_TRY(icpx_reserve(ctx, ctx->scratch_q, n * sizeof(float4)));
-    ICPX_TRY(icpx_reserve(ctx, ctx->edt_counters, 4 * sizeof(unsigned long long)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_counters, 8 * sizeof(unsigned long long)));
     // keep the caller-order copy; sorted_pts is rewritten by the gather
     ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, ctx->sorted_pts.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     for (int attempt = 0; attempt < 2; attempt++) {

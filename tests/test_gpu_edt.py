@@ -51,17 +51,18 @@ def test_edt_dense_random_and_spill(gpu_ctx, oracle):
     assert gpu_ctx.edt_info()["dropped"] == dropped
 
 
-def test_edt_large_div_uses_wide_entries(gpu_ctx, oracle, bunny045):
-    """div > 511 switches the x pass to its 6-byte stack entries."""
+def test_edt_large_div(gpu_ctx, oracle, bunny045):
+    """div > 511: ten-bit site indices and values above 2^19 in the packed stack entries."""
     _build_and_check(gpu_ctx, oracle, np.ascontiguousarray(bunny045[::3]), 520)
 
 
-@pytest.mark.parametrize("cap", ["2", "7"])
-def test_edt_spill_tier(oracle, bunny045, cap, monkeypatch):
-    """A tiny LDS capacity pushes almost every stack level into the spill tier."""
+@pytest.mark.parametrize("tune", ["4,2,0", "2,7,4", "1,3,2", "3,5,30", "4,14,1"])
+def test_edt_pool_and_spill_tiers(oracle, bunny045, tune, monkeypatch):
+    """Tiny private LDS capacities push stack levels into the shared pool and, once that is exhausted (or
+    absent), into the global spill buffer of a second build attempt. tune = groups,levels,chunks."""
     from icp_amd.api import Context
-    monkeypatch.setenv("ICPX_EDT_CAP_ZY", cap)
-    monkeypatch.setenv("ICPX_EDT_CAP_X", cap)
+    monkeypatch.setenv("ICPX_EDT_ZY", tune)
+    monkeypatch.setenv("ICPX_EDT_X", tune)
     ctx = Context(0)
     try:
         _build_and_check(ctx, oracle, bunny045, 100)
