@@ -135,22 +135,24 @@ def main():
     ctx.sync()
     barrier()
     t0 = time.perf_counter()
-    stage_ms = ctx.edt_rebuild_timed(args.steps)     # K back-to-back builds, HIP events between the stages
+    # K back-to-back builds; every 8th one carries start/stop HIP events on each launch (events cost stream time)
+    stage_ms = ctx.edt_rebuild_timed(args.steps, sample_every=8)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     value = world * voxels * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
-    stage_names = ["clear", "splat", "census", "pass_zy", "pass_x"]
-    per_stage = {k: float(v) / args.steps for k, v in zip(stage_names, stage_ms)}
+    stage_names = ["splat", "census", "pass_zy", "pass_x"]
+    per_stage = {k: float(v) for k, v in zip(stage_names, stage_ms)}
     dom = "pass_x"
     alg_bytes = 8.0 * voxels                       # one int32 read + one int32 write per voxel
     achieved = alg_bytes / (per_stage[dom] * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k_edt_pass_x", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic("k_edt_pass_x"),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_stage[dom],
-                "whole_build": {"algorithmic_bytes": 24.0 * voxels, "GB/s": 24.0 * voxels / (sum(per_stage.values()) * 1e-3) / 1e9,
-                                "frac": 24.0 * voxels / (sum(per_stage.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "whole_build": {"algorithmic_bytes": 24.0 * voxels, "GB/s": 24.0 * voxels / (ms_per_step * 1e-3) / 1e9,
+                                "frac": 24.0 * voxels / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "kernel_ms_sum": sum(per_stage.values())},
                 "stage_ms": per_stage}
 
     extra = {}

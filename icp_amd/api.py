@@ -127,11 +127,13 @@ class Context:
     def edt_rebuild_async(self):
         self._ck(self._lib.icpx_edt_rebuild_async(self._h))
 
-    def edt_rebuild_timed(self, reps):
-        """Summed per-stage milliseconds over `reps` rebuilds: clear, splat, census, pass zy, pass x."""
-        ms = (C.c_float * 5)()
-        self._ck(self._lib.icpx_edt_rebuild_timed(self._h, reps, ms))
-        return np.array(list(ms), np.float64)
+    def edt_rebuild_timed(self, reps, sample_every=1):
+        """`reps` rebuilds back to back; returns the average kernel milliseconds per stage (splat, census, pass zy,
+        pass x) over the builds that carried events (every `sample_every`-th)."""
+        ms = (C.c_float * 4)()
+        n = C.c_int()
+        self._ck(self._lib.icpx_edt_rebuild_timed(self._h, reps, sample_every, ms, C.byref(n)))
+        return np.array(list(ms), np.float64) / max(n.value, 1)
 
     def edt_info(self):
         div = C.c_uint32(); mn = (C.c_float * 3)(); cell = C.c_float(); occ = C.c_uint64(); dr = C.c_uint64()

@@ -62,11 +62,12 @@ struct icpx_ctx {
     // chunks per workgroup. 4 x 28 x 64 x 6 bytes + 40 chunks x 48 bytes + header = 47 KiB: three
     // workgroups (12 waves) per CU; measured best on the 300^3 bunny grid among the shapes tried.
     EnvTune edt_zy{4, 28, 40}, edt_x{4, 28, 40};
-    DevBuf edt_bits;         // div*div*edt_words uint64 occupancy bits
+    DevBuf edt_bits;         // div*div*edt_words uint64 occupancy bits, then two sets of 8 uint64 counters (alternate builds)
+    int edt_epoch = 0;       // counter set of the latest build
     DevBuf edt_rowlist;      // [x][chunk][k] 16-byte records of the non-empty rows of every plane (see k_edt_census)
     DevBuf edt_rowcnt;       // div int
     DevBuf edt_planelist;    // int32 ascending non-empty planes, padded with the last one to a multiple of 16 plus 16
-    DevBuf edt_counters;     // uint64 x 8: {occupied voxels, dropped points, nplanes, unused, overflow zy, overflow x, -, -}
+    DevBuf edt_counters;     // scratch words of the search-grid build
     DevBuf edt_spill;        // NULL until a build overflowed the LDS stacks: [level - cap][group][row] 8-byte entries
     DevBuf edt_plane;        // div^3 int32: in-plane squared distances (only non-empty planes written)
     DevBuf edt_sq;           // div^3 int32: squared EDT, [x][y][z]

@@ -16,6 +16,8 @@
 // Memory traffic: the only full-size arrays are the in-plane distances (written for non-empty planes,
 // read once) and the output; the occupancy is 1 bit per voxel and stays in L2.
 // How the envelope scans are organised: see "lower envelope of parabolas" below.
+#include <hip/hip_ext.h>
+
 #include "icpx_ctx.h"
 #include "icpx_edt_dev.h"
 
@@ -44,7 +46,7 @@ __global__ void k_edt_splat(const float* __restrict__ pts, size_t n, float mnx, 
     atomicOr(&bits[((size_t)ix * div + iy) * W + (iz >> 6)], 1ull << (iz & 63));
 }
 
-// ---- census: one wave per plane x ------------------------------------------------------------------------
+// ---- census ------------------------------------------------------------------------------------------------
 // For every non-empty row (x, y) and every 64-wide z chunk c the census writes one 16-byte record that
 // pass zy consumes: the chunk's own occupancy word, the nearest set bit below / above the chunk, and y.
 // Records of one (x, c) are contiguous in the order of ascending y, so pass zy streams them.
@@ -55,55 +57,86 @@ struct RowRec {
     int y;                  // row index (the envelope site)
 };
 
-__global__ __launch_bounds__(64) void k_edt_census(const u64* __restrict__ bits, int div, int W, RowRec* __restrict__ recs,
-                                                   int* __restrict__ rowcnt, u64* __restrict__ counters) {
-    const int x = blockIdx.x, lane = threadIdx.x;
-    int cnt = 0;
+// One workgroup per plane x, one wave per 64 rows y. A lane reads the occupancy words of its row into
+// registers and zeroes them in memory, which leaves the bit array clear for the next build (nothing after
+// the census reads it). The workgroup that finishes last (ticket in counters[6]) also writes the ascending
+// list of the non-empty planes as int32, padded with copies of the last entry up to `padded` entries so
+// that pass x can prefetch whole groups without bounds checks, and zeroes the counter set of the next
+// build.
+constexpr int EDT_MAXW = (ICPX_MAX_DIV + 63) / 64;
+
+__global__ __launch_bounds__(1024) void k_edt_census(u64* __restrict__ bits, int div, int W, RowRec* __restrict__ recs,
+                                                     int* __restrict__ rowcnt, u64* __restrict__ counters, u64* __restrict__ next_counters,
+                                                     int padded, int* __restrict__ planelist) {
+    __shared__ int wave_cnt[16];
+    __shared__ unsigned wave_occ[16];
+    __shared__ bool is_last;
+    const int x = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int y = wv * 64 + lane;
+    u64* row = bits + ((size_t)x * div + (y < div ? y : 0)) * W;
+    u64 wd[EDT_MAXW];
     unsigned occ = 0;
-    for (int base = 0; base < div; base += 64) {
-        const int y = base + lane;
-        bool any = false;
-        const u64* row = bits + ((size_t)x * div + (y < div ? y : 0)) * W;
-        if (y < div)
-            for (int w = 0; w < W; w++) { u64 v = row[w]; any |= v != 0; occ += __popcll(v); }
-        const u64 m = __ballot(any);
-        if (any) {
-            const int k = cnt + __popcll(m & ((1ull << lane) - 1));
-            int below = 0;   // running: 1 + highest set position seen in words < c
-            for (int c = 0; c < W; c++) {
-                int above = 0xffff;
-                for (int j = c + 1; j < W; j++) { u64 v = row[j]; if (v) { above = 64 * j + (__ffsll((long long)v) - 1); break; } }
+    bool any = false;
+#pragma unroll
+    for (int w = 0; w < EDT_MAXW; w++) {
+        wd[w] = w < W && y < div ? row[w] : 0ull;
+        any |= wd[w] != 0;
+        occ += __popcll(wd[w]);
+    }
+    if (any) {
+#pragma unroll
+        for (int w = 0; w < EDT_MAXW; w++)
+            if (wd[w]) row[w] = 0ull;
+    }
+    const u64 m = __ballot(any);
+    for (int o = 32; o > 0; o >>= 1) occ += __shfl_xor(occ, o);
+    if (lane == 0) { wave_cnt[wv] = __popcll(m); wave_occ[wv] = occ; }
+    __syncthreads();
+    int before = 0, cnt = 0;
+    unsigned occ_all = 0;
+    for (int w = 0; w < nw; w++) { before += w < wv ? wave_cnt[w] : 0; cnt += wave_cnt[w]; occ_all += wave_occ[w]; }
+    if (any) {
+        const int k = before + __popcll(m & ((1ull << lane) - 1));
+        int above[EDT_MAXW];   // position of the nearest set bit in higher words, 0xffff = none
+        int nxt = 0xffff;
+#pragma unroll
+        for (int c = EDT_MAXW - 1; c >= 0; c--) {
+            above[c] = nxt;
+            if (wd[c]) nxt = 64 * c + (__ffsll((long long)wd[c]) - 1);
+        }
+        int below = 0;         // running: 1 + highest set position seen in words < c
+#pragma unroll
+        for (int c = 0; c < EDT_MAXW; c++) {
+            if (c < W) {
                 RowRec r;
-                r.own = row[c]; r.below = (unsigned short)below; r.above = (unsigned short)above; r.y = y;
+                r.own = wd[c]; r.below = (unsigned short)below; r.above = (unsigned short)above[c]; r.y = y;
                 recs[((size_t)x * W + c) * div + k] = r;
-                if (r.own) below = 64 * c + 64 - __clzll(r.own);
+                if (wd[c]) below = 64 * c + 64 - __clzll(wd[c]);
             }
         }
-        cnt += __popcll(m);
     }
-    for (int o = 32; o > 0; o >>= 1) occ += __shfl_xor(occ, o);
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         rowcnt[x] = cnt;
-        if (occ) atomicAdd(&counters[0], (u64)occ);
+        if (occ_all) atomicAdd(&counters[0], (u64)occ_all);
+        __threadfence();
+        is_last = atomicAdd(&counters[6], 1ull) == (u64)(gridDim.x - 1);
     }
-}
-
-// Ascending list of the non-empty planes as int32, padded with copies of the last entry up to
-// `padded` entries so that pass x can prefetch whole groups without bounds checks.
-__global__ __launch_bounds__(64) void k_edt_planes(const int* __restrict__ rowcnt, int div, int padded, int* __restrict__ planelist,
-                                                   u64* __restrict__ counters) {
-    const int lane = threadIdx.x;
-    int cnt = 0, last = 0;
+    __syncthreads();
+    if (!is_last || wv != 0) return;
+    __threadfence();
+    const volatile int* rc = rowcnt;
+    int np = 0, last = 0;
     for (int base = 0; base < div; base += 64) {
-        const int x = base + lane;
-        const bool any = x < div && rowcnt[x] > 0;
-        const u64 m = __ballot(any);
-        if (any) planelist[cnt + __popcll(m & ((1ull << lane) - 1))] = x;
-        if (m) last = base + 63 - __clzll(m);
-        cnt += __popcll(m);
+        const int px = base + lane;
+        const bool pany = px < div && rc[px] > 0;
+        const u64 pm = __ballot(pany);
+        if (pany) planelist[np + __popcll(pm & ((1ull << lane) - 1))] = px;
+        if (pm) last = base + 63 - __clzll(pm);
+        np += __popcll(pm);
     }
-    for (int k = cnt + lane; k < padded; k += 64) planelist[k] = last;
-    if (lane == 0) counters[2] = (u64)cnt;
+    for (int k = np + lane; k < padded; k += 64) planelist[k] = last;
+    if (lane == 0) counters[2] = (u64)np;
+    if (lane < 8) next_counters[lane] = 0ull;
 }
 
 // floor(N / D) for 0 <= N < 2^23, 1 <= D < 2^12, exact whenever the quotient is below 2^12 (the callers
@@ -134,8 +167,8 @@ __device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70)
 // same 64 rows in every wave), then, after a barrier, wave g evaluates the g-th part of the positions
 // against all G stacks and takes the minimum. The stacks are never merged.
 //
-// A stack entry is {site s, value v} in one dword (s << 22 | v; v < 2^22 because div <= 1023) and the first
-// position t the entry owns among the entries of its own stack in a halfword. Where the levels live:
+// A stack entry is {site s, a = s^2 + value} in one dword (s << 22 | a; a <= 3 (div - 1)^2 < 2^22 because
+// div <= 1023) and the first position t the entry owns among the entries of its own stack in a halfword. Where the levels live:
 //   level < cap                 LDS, [group][level][lane] (conflict-free)
 //   cap <= level < cap + 32     LDS pool shared by the workgroup: chunks of 8 levels, handed out with an
 //                               atomic counter the first time a stack reaches them; the four chunk ids of
@@ -215,8 +248,8 @@ struct Env {
 // Scan state of one stack: the top entry unpacked, the entry below it packed.
 struct EnvTop {
     int q;                  // index of the top entry, -1 = empty
-    int ts, tv, tt;         // top: site, value, start
-    unsigned tw;            // top, packed
+    int ts, ta, tt2;        // top: site, a = s^2 + value, twice its start
+    unsigned tw; int tt;    // top, packed, and its start
     unsigned bw; int bt;    // entry below the top (undefined when q < 1)
     int wb, tb;             // LDS byte addresses of level 0 of this stack
     unsigned tab;           // pool chunk ids of this stack
@@ -224,26 +257,31 @@ struct EnvTop {
 
 template <int G>
 __device__ __forceinline__ void env_init(const Env<G>& E, int g, EnvTop& e) {
-    e = EnvTop{-1, 0, 0, 0, 0u, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu};
+    e = EnvTop{-1, 0, 0, 0, 0u, 0, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu};
 }
 
 // Adds site u (ascending) with value v to the stack of group g: pop while the new parabola is lower at
-// the start of the top entry, then enter it at the first position where it is lower than the top, if
-// that position is inside the row (src/testLDT.cpp:136-150). Reads below the bottom of a stack return
-// whatever precedes it in LDS and are never used.
+// the start t of the top entry, then enter it at the first position where it is lower than the top, if
+// that position is inside the row (src/testLDT.cpp:136-150). With a = s^2 + v the parabola of a site is
+// f(p) = p^2 - 2 p s + a, so "new lower than top at t" is 2 t (u - s) + (a_top - a_u) > 0 and the
+// crossing is (a_u - a_top) / (2 (u - s)); entries carry a instead of v. Reads below the bottom of a
+// stack return whatever precedes it in LDS and are never used.
 template <int G>
 __device__ __forceinline__ void env_add(const Env<G>& E, int g, EnvTop& e, int u, int v, int div) {
-    while (e.q >= 0 && sqdist(e.tt, e.ts, e.tv) > sqdist(e.tt, u, v)) {
-        e.tw = e.bw; e.ts = (int)(e.bw >> ENV_VB); e.tv = (int)(e.bw & ENV_VMASK); e.tt = e.bt;
+    const int au = (u & 0x3ff) * (u & 0x3ff) + v;
+    int d, dd;
+    for (;;) {
+        d = u - e.ts; dd = e.ta - au;
+        if (!(e.q >= 0 && __mul24(e.tt2, d) + dd > 0)) break;
+        e.tw = e.bw; e.ts = (int)(e.bw >> ENV_VB); e.ta = (int)(e.bw & ENV_VMASK); e.tt = e.bt; e.tt2 = 2 * e.bt;
         e.q--;
         E.load(g, e.wb, e.tb, e.tab, e.q - 1, e.bw, e.bt);
     }
-    const int du = u - e.ts;
-    int w = 1 + floordiv_pos(__mul24(u + e.ts, du) + (v - e.tv), 2 * du);
+    int w = 1 + floordiv_pos(-dd, 2 * d);
     if (e.q < 0) w = 0;
     if (w < div) {
         e.bw = e.tw; e.bt = e.tt;
-        e.tw = ((unsigned)u << ENV_VB) | (unsigned)v; e.ts = u; e.tv = v; e.tt = w;
+        e.tw = ((unsigned)u << ENV_VB) | (unsigned)au; e.ts = u; e.ta = au; e.tt = w; e.tt2 = 2 * w;
         e.q++;
         E.store(g, e.wb, e.tb, e.tab, e.q, e.tw, w);
     }
@@ -286,8 +324,7 @@ __device__ __forceinline__ void env_seek(const Env<G>& E, int j, EnvCur& c, int 
 // HIGH: some lane's cursor may still be above the private levels.
 template <int G, bool HIGH>
 __device__ __forceinline__ int env_eval(const Env<G>& E, int j, EnvCur& c, int p) {
-    const int d = (p & 0x3ff) - (int)(c.cw >> ENV_VB);      // |d| <= 1023: the product is a 24-bit multiply
-    const int v = d * d + (int)(c.cw & ENV_VMASK);
+    const int v = (int)(c.cw >> ENV_VB) * (-2 * (p & 0x3ff)) + (int)(c.cw & ENV_VMASK);   // f(p) - p^2; a 24-bit multiply-add
     c.lvl -= p == c.ct ? 1 : 0;
     if (HIGH) E.load(j, c.wb, c.tb, c.tab, c.lvl, c.cw, c.ct);
     else { c.cw = E.W(c.wb, c.lvl); c.ct = E.T(c.tb, c.lvl); }
@@ -310,14 +347,15 @@ __device__ __forceinline__ void env_write(const Env<G>& E, int* __restrict__ out
         int v = 0x7fffffff;
 #pragma unroll
         for (int j = 0; j < G; j++) v = min(v, env_eval<G, true>(E, j, cur[j], p));
-        if (E.active) (out + (size_t)p * stride)[lane_off] = v;
+        if (E.active) (out + (size_t)p * stride)[lane_off] = v + p * p;
         p--;
     }
+#pragma unroll 2
     for (; p >= plo; p--) {
         int v = 0x7fffffff;
 #pragma unroll
         for (int j = 0; j < G; j++) v = min(v, env_eval<G, false>(E, j, cur[j], p));
-        if (E.active) (out + (size_t)p * stride)[lane_off] = v;
+        if (E.active) (out + (size_t)p * stride)[lane_off] = v + p * p;
     }
 }
 
@@ -445,6 +483,13 @@ __global__ void k_edt_lookup(const int* __restrict__ sq, int div, float mnx, flo
 
 }  // namespace
 
+// Two sets of uint64 x 8 behind the occupancy bits, used by alternate builds: {occupied voxels, dropped
+// points, non-empty planes, -, overflow pass zy, overflow pass x, census ticket, -}
+static u64* edt_counter_set(const icpx_ctx* ctx, int set) {
+    return ctx->edt_bits.as<u64>() + (size_t)ctx->div * ctx->div * ctx->edt_words + 8 * (set & 1);
+}
+static u64* edt_counters(const icpx_ctx* ctx) { return edt_counter_set(ctx, ctx->edt_epoch); }
+
 // Size of the spill buffer of the envelope passes at the current resolution: one 8-byte entry per row, site
 // group and level beyond the private ones (a group holds at most ceil(div / groups) sites).
 static size_t edt_spill_bytes(const icpx_ctx* ctx) {
@@ -456,7 +501,15 @@ static size_t edt_spill_bytes(const icpx_ctx* ctx) {
     return need;
 }
 
-// ev: NULL, or ICPX_EDT_NSTAGES + 1 events recorded around the stages (clear, splat, census, pass zy, pass x).
+// Launch on the stream; with ev != NULL the dispatch carries the start / stop events of its stage, which
+// time the kernel itself (no extra packets on the stream).
+template <class K, class... A>
+static void edt_launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipEvent_t* ev, int stage, A... args) {
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, s, ev[2 * stage], ev[2 * stage + 1], 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, s, args...);
+}
+
+// ev: NULL, or 2 * ICPX_EDT_NSTAGES events, a (start, stop) pair per stage: splat, census, pass zy, pass x.
 static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
     const int div = (int)ctx->div, W = ctx->edt_words;
     const int nchunk = (div + 63) / 64;
@@ -464,60 +517,56 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
     // A spill buffer left from a build at a lower resolution is too small for this one: run without it
     // (the build then reports the overflow, if any, and the buffer is grown).
     uint2* spill = ctx->edt_spill.cap >= edt_spill_bytes(ctx) ? ctx->edt_spill.as<uint2>() : nullptr;
-    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[0], s));
-    ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_bits.p, 0, (size_t)div * div * W * sizeof(u64), s));
-    ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_counters.p, 0, 8 * sizeof(u64), s));
-    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(k_edt_splat, dim3((unsigned)((ctx->nt + 255) / 256)), dim3(256), 0, s, ctx->tgt_xyz.as<float>(), ctx->nt,
-                       ctx->edt_min[0], ctx->edt_min[1], ctx->edt_min[2], ctx->edt_cell, div, W, ctx->edt_bits.as<u64>(),
-                       ctx->edt_counters.as<u64>());
-    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(k_edt_census, dim3(div), dim3(64), 0, s, ctx->edt_bits.as<u64>(), div, W, ctx->edt_rowlist.as<RowRec>(),
-                       ctx->edt_rowcnt.as<int>(), ctx->edt_counters.as<u64>());
-    hipLaunchKernelGGL(k_edt_planes, dim3(1), dim3(64), 0, s, ctx->edt_rowcnt.as<int>(), div, (div + 15) / 16 * 16 + 16,
-                       ctx->edt_planelist.as<int>(), ctx->edt_counters.as<u64>());
-    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[3], s));
+    // No clearing here: the census of the previous build left the occupancy bits zero and zeroed this
+    // build's counter set (edt_prepare clears everything when the buffers are (re)allocated or resized).
+    ctx->edt_epoch ^= 1;
+    u64* counters = edt_counters(ctx);
+    edt_launch(k_edt_splat, dim3((unsigned)((ctx->nt + 255) / 256)), dim3(256), 0, s, ev, 0, ctx->tgt_xyz.as<float>(), ctx->nt,
+               ctx->edt_min[0], ctx->edt_min[1], ctx->edt_min[2], ctx->edt_cell, div, W, ctx->edt_bits.as<u64>(), counters);
+    edt_launch(k_edt_census, dim3(div), dim3(64 * nchunk), 0, s, ev, 1, ctx->edt_bits.as<u64>(), div, W, ctx->edt_rowlist.as<RowRec>(),
+               ctx->edt_rowcnt.as<int>(), counters, edt_counter_set(ctx, ctx->edt_epoch ^ 1), (div + 15) / 16 * 16 + 16,
+               ctx->edt_planelist.as<int>());
     {
         const int G = ctx->edt_zy.groups, cap = ctx->edt_zy.cap, nch = ctx->edt_zy.chunks;
         auto zy = G == 1 ? k_edt_pass_zy<1> : G == 2 ? k_edt_pass_zy<2> : G == 3 ? k_edt_pass_zy<3> : k_edt_pass_zy<4>;
-        hipLaunchKernelGGL(zy, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ctx->edt_rowlist.as<RowRec>(),
-                           ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, ctx->edt_counters.as<u64>(), div,
-                           W, cap, nch);
+        edt_launch(zy, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ev, 2, (const RowRec*)ctx->edt_rowlist.as<RowRec>(),
+                   (const int*)ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, counters, div, W, cap, nch);
     }
-    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[4], s));
     {
         const int G = ctx->edt_x.groups, cap = ctx->edt_x.cap, nch = ctx->edt_x.chunks;
         auto px = G == 1 ? k_edt_pass_x<1> : G == 2 ? k_edt_pass_x<2> : G == 3 ? k_edt_pass_x<3> : k_edt_pass_x<4>;
-        hipLaunchKernelGGL(px, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ctx->edt_plane.as<int>(),
-                           ctx->edt_planelist.as<int>(), ctx->edt_counters.as<u64>(), ctx->edt_sq.as<int>(), spill, div,
-                           nchunk, cap, nch);
+        edt_launch(px, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ev, 3, (const int*)ctx->edt_plane.as<int>(),
+                   (const int*)ctx->edt_planelist.as<int>(), counters, ctx->edt_sq.as<int>(), spill, div, nchunk, cap, nch);
     }
-    if (ev) ICPX_CHECK_HIP(ctx, hipEventRecord(ev[5], s));
     return icpx_launch_check(ctx, "EDT kernels");
 }
 
 int icpx_edt_run(icpx_ctx* ctx) { return edt_run_impl(ctx, nullptr); }
 
-extern "C" int icpx_edt_rebuild_timed(icpx_ctx* ctx, int reps, float stage_ms[ICPX_EDT_NSTAGES]) {
+extern "C" int icpx_edt_rebuild_timed(icpx_ctx* ctx, int reps, int sample_every, float stage_ms[ICPX_EDT_NSTAGES], int* sampled) {
     if (!ctx) return ICPX_EINVAL;
     if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_rebuild_timed: no EDT has been built yet");
-    if (reps < 1 || !stage_ms) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_rebuild_timed: bad arguments");
+    if (reps < 1 || sample_every < 1 || !stage_ms || !sampled) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_rebuild_timed: bad arguments");
     ICPX_TRY(icpx_bind(ctx));
-    std::vector<hipEvent_t> ev((size_t)reps * (ICPX_EDT_NSTAGES + 1));
+    const int ns = (reps + sample_every - 1) / sample_every;
+    std::vector<hipEvent_t> ev((size_t)ns * 2 * ICPX_EDT_NSTAGES);
     for (auto& e : ev) ICPX_CHECK_HIP(ctx, hipEventCreate(&e));
     int rc = ICPX_OK;
-    for (int r = 0; r < reps && rc == ICPX_OK; r++) rc = edt_run_impl(ctx, ev.data() + (size_t)r * (ICPX_EDT_NSTAGES + 1));
+    for (int r = 0; r < reps && rc == ICPX_OK; r++)
+        rc = edt_run_impl(ctx, r % sample_every == 0 ? ev.data() + (size_t)(r / sample_every) * 2 * ICPX_EDT_NSTAGES : nullptr);
     if (rc == ICPX_OK) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { ctx->set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e)); rc = ICPX_EHIP; }
     }
     for (int k = 0; k < ICPX_EDT_NSTAGES; k++) stage_ms[k] = 0.f;
-    for (int r = 0; r < reps && rc == ICPX_OK; r++)
+    for (int r = 0; r < ns && rc == ICPX_OK; r++)
         for (int k = 0; k < ICPX_EDT_NSTAGES; k++) {
             float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, ev[(size_t)r * (ICPX_EDT_NSTAGES + 1) + k], ev[(size_t)r * (ICPX_EDT_NSTAGES + 1) + k + 1]);
+            const hipEvent_t* e2 = &ev[((size_t)r * ICPX_EDT_NSTAGES + k) * 2];
+            (void)hipEventElapsedTime(&ms, e2[0], e2[1]);
             stage_ms[k] += ms;
         }
+    *sampled = ns;
     for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
 }
@@ -530,11 +579,11 @@ static int edt_prepare(icpx_ctx* ctx, uint32_t div) {
     ctx->div = div;
     ctx->edt_words = (int)((div + 63) / 64);
     const size_t n3 = (size_t)div * div * div;
-    ICPX_TRY(icpx_reserve(ctx, ctx->edt_bits, (size_t)div * div * ctx->edt_words * sizeof(u64)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_bits, ((size_t)div * div * ctx->edt_words + 16) * sizeof(u64)));   // + two counter sets
+    ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_bits.p, 0, ((size_t)div * div * ctx->edt_words + 16) * sizeof(u64), ctx->stream));
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_rowlist, (size_t)div * div * ctx->edt_words * 16));   // RowRec records
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_rowcnt, (size_t)div * sizeof(int)));
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_planelist, (size_t)((div + 15) / 16 * 16 + 16) * sizeof(int)));
-    ICPX_TRY(icpx_reserve(ctx, ctx->edt_counters, 8 * sizeof(u64)));
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_plane, n3 * sizeof(int)));
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_sq, n3 * sizeof(int)));
     return ICPX_OK;
@@ -549,7 +598,7 @@ extern "C" int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[
     for (int attempt = 0; attempt < 2; attempt++) {
         ICPX_TRY(icpx_edt_run(ctx));
         u64 counters[8];
-        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, ctx->edt_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, edt_counters(ctx), sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
         ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (counters[0] == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "EDT build: no target point falls inside the grid");
         if (!counters[4] && !counters[5]) break;
@@ -601,7 +650,7 @@ extern "C" int icpx_edt_info(icpx_ctx* ctx, uint32_t* div, float min3[3], float*
     if (cell_len) *cell_len = ctx->edt_cell;
     if (occupied || dropped) {
         u64 counters[4];
-        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, ctx->edt_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, edt_counters(ctx), sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
         ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (occupied) *occupied = counters[0];
         if (dropped) *dropped = counters[1];

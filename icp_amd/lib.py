@@ -44,7 +44,7 @@ ICPX_SYMBOLS = {
     "icpx_edt_build": (C.c_int, [C.c_void_p, C.c_uint32]),
     "icpx_edt_build_box": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_float]),
     "icpx_edt_rebuild_async": (C.c_int, [C.c_void_p]),
-    "icpx_edt_rebuild_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "icpx_edt_rebuild_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "icpx_edt_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "icpx_edt_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "icpx_edt_grid_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -117,12 +117,15 @@ int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[3], float c
  * icpx_edt_build* call are reused): the timed region of the EDT benchmark. */
 int icpx_edt_rebuild_async(icpx_ctx* ctx);
 
-/* Runs the same kernels `reps` times back to back on the stream with HIP events recorded between the
- * stages, waits, and returns the summed duration of every stage in milliseconds: clear, splat, census,
- * pass zy (z scan + y envelope), pass x. The reference times its constructor the same way with
- * omp_get_wtime (src/testLDT.cpp:43, :209). */
-#define ICPX_EDT_NSTAGES 5
-int icpx_edt_rebuild_timed(icpx_ctx* ctx, int reps, float stage_ms[ICPX_EDT_NSTAGES]);
+/* Runs the same kernels `reps` times back to back on the stream and waits. In every `sample_every`-th
+ * build (the first one included) each launch carries its own start and stop HIP events; stage_ms
+ * receives the kernel time of every stage summed over those builds, in milliseconds: splat, census,
+ * pass zy (z scan + y envelope), pass x; *sampled receives their number. Events cost stream time, so
+ * sample_every > 1 keeps the loop close to what icpx_edt_rebuild_async alone would take; the gaps between
+ * kernels belong to no stage, the caller's clock around the call sees them. The reference times its
+ * constructor with omp_get_wtime (src/testLDT.cpp:43, :209). */
+#define ICPX_EDT_NSTAGES 4
+int icpx_edt_rebuild_timed(icpx_ctx* ctx, int reps, int sample_every, float stage_ms[ICPX_EDT_NSTAGES], int* sampled);
 
 /* LDT's public fields (src/testLDT.cpp:31-35): div, _min, cellLen; plus the occupied-voxel count and
  * the number of points dropped by the splat. Any output pointer may be NULL. */
