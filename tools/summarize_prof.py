@@ -12,7 +12,8 @@ def short(name):
     return head.replace("void ", "").split("::")[-1].strip()
 
 
-src = glob.glob(f"{base}/trace/*/*_kernel_stats.csv")[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)   # gpurun merges into gpurun_out/: older runs may still be there
+src = newest(f"{base}/trace/*/*_kernel_stats.csv")
 with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
     w = csv.writer(f)
     w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
@@ -23,6 +24,7 @@ for d in ("fetch", "write", "sq"):
     fs = glob.glob(f"{base}/{d}/*/*_counter_collection.csv")
     if not fs:
         continue
+    fs = [max(fs, key=os.path.getmtime)]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
         if "k_edt" in r["Kernel_Name"]:
