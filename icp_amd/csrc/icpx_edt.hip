@@ -144,7 +144,7 @@ __global__ __launch_bounds__(1024) void k_edt_census(u64* __restrict__ bits, int
 // at most 2 there). One float reciprocal, one multiply, one correction step in each direction.
 __device__ __forceinline__ int floordiv_pos(int N, int D) {
     int k = (int)((float)N * __builtin_amdgcn_rcpf((float)D));
-    const int r = N - k * D;
+    const int r = N - __mul24(k, D);      // |k| < 2^13 wherever the result matters, D < 2^12
     k += (r >= D) - (r < 0);
     return k;
 }
@@ -187,9 +187,10 @@ struct Env {
     char* lds;
     int cap, nch, lane;
     int off_w, off_t, off_pw, off_pt;   // byte offsets: words [G][cap][64] u32, starts [G][cap][64] u16, pool words, pool starts
-    uint2* sp;               // spill buffer or NULL
+    uint2* sp;               // spill buffer (already offset to this lane's row) or NULL
     int sp_levels;           // levels the spill buffer holds
-    size_t sp_rows, sp_row;  // rows in the pass, this lane's row
+    unsigned sp_stride;      // entries between consecutive levels of one stack (groups x rows of the pass)
+    unsigned sp_gstride;     // entries between the stacks of consecutive groups (rows of the pass)
     u64* ovf;                // overflow counter word
     bool active;             // lane owns a row (idle lanes shadow the last row and never store)
 
@@ -202,7 +203,7 @@ struct Env {
     __device__ __forceinline__ int tbase(int g) const { return off_t + g * cap * 128 + lane * 2; }
     __device__ __forceinline__ unsigned& W(int wb, int level) const { return *reinterpret_cast<unsigned*>(lds + wb + (level << 8)); }
     __device__ __forceinline__ unsigned short& T(int tb, int level) const { return *reinterpret_cast<unsigned short*>(lds + tb + (level << 7)); }
-    __device__ __forceinline__ size_t spslot(int g, int level) const { return ((size_t)(level - cap) * G + g) * sp_rows + sp_row; }
+    __device__ __forceinline__ size_t spslot(int g, int level) const { return (size_t)(unsigned)(level - cap) * sp_stride + (size_t)g * sp_gstride; }
 
     // Pool slot of an overflow level, -1 when the level is not in the pool.
     __device__ __forceinline__ int pool_slot(unsigned tab, int level) const {
@@ -253,11 +254,12 @@ struct EnvTop {
     unsigned bw; int bt;    // entry below the top (undefined when q < 1)
     int wb, tb;             // LDS byte addresses of level 0 of this stack
     unsigned tab;           // pool chunk ids of this stack
+    int deepest;            // largest q so far
 };
 
 template <int G>
 __device__ __forceinline__ void env_init(const Env<G>& E, int g, EnvTop& e) {
-    e = EnvTop{-1, 0, 0, 0, 0u, 0, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu};
+    e = EnvTop{-1, 0, 0, 0, 0u, 0, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu, -1};
 }
 
 // Adds site u (ascending) with value v to the stack of group g: pop while the new parabola is lower at
@@ -283,14 +285,18 @@ __device__ __forceinline__ void env_add(const Env<G>& E, int g, EnvTop& e, int u
         e.bw = e.tw; e.bt = e.tt;
         e.tw = ((unsigned)u << ENV_VB) | (unsigned)au; e.ts = u; e.ta = au; e.tt = w; e.tt2 = 2 * w;
         e.q++;
+        e.deepest = max(e.deepest, e.q);
         E.store(g, e.wb, e.tb, e.tab, e.q, e.tw, w);
     }
 }
 
 // Ends the scan of group g: publishes depth and chunk table (a group without sites gets one entry that
-// loses against every real one).
+// loses against every real one) and reports the deepest level count any stack of the wave reached, which
+// the host uses to size the private levels of later builds.
 template <int G>
-__device__ __forceinline__ void env_finish(const Env<G>& E, int g, EnvTop& e) {
+__device__ __forceinline__ void env_finish(const Env<G>& E, int g, EnvTop& e, int deepest, u64* max_depth) {
+    for (int o = 32; o; o >>= 1) deepest = max(deepest, __shfl_xor(deepest, o));
+    if (E.lane == 0 && (u64)deepest > *(volatile u64*)max_depth) atomicMax(max_depth, (u64)deepest);
     if (e.q < 0) { e.q = 0; E.store(g, e.wb, e.tb, e.tab, 0, ENV_VMASK, 0); }
     E.depth(g) = (unsigned short)e.q;
     E.table(g) = e.tab;
@@ -346,7 +352,8 @@ __device__ __forceinline__ void env_write(const Env<G>& E, int* __restrict__ out
         if (p < plo || !__any(high)) break;
         int v = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < G; j++) v = min(v, env_eval<G, true>(E, j, cur[j], p));
+        for (int j = 0; j < G; j++)   // only the stacks that are still above pay for the general read-back
+            v = min(v, __any(cur[j].lvl >= E.cap) ? env_eval<G, true>(E, j, cur[j], p) : env_eval<G, false>(E, j, cur[j], p));
         if (E.active) (out + (size_t)p * stride)[lane_off] = v + p * p;
         p--;
     }
@@ -374,8 +381,9 @@ __device__ __forceinline__ Env<G> env_setup(unsigned* lds, int cap, int nch, int
     E.off_t = E.off_w + G * cap * 256;
     E.off_pw = E.off_t + G * cap * 128;
     E.off_pt = E.off_pw + nch * ENV_CHUNK * 4;
-    E.sp = sp; E.sp_levels = max((div + G - 1) / G + 1 - cap, 1);   // the host sizes the buffer with the same rule
-    E.sp_rows = rows; E.sp_row = row; E.ovf = ovf; E.active = active;
+    E.sp = sp ? sp + row : nullptr;
+    E.sp_levels = max((div + G - 1) / G + 1 - cap, 1);   // the host sizes the buffer with the same rule
+    E.sp_gstride = (unsigned)rows; E.sp_stride = (unsigned)rows * G; E.ovf = ovf; E.active = active;
     if (threadIdx.x == 0) *E.counter() = 0;
     __syncthreads();
     return E;
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict
             env_add(E, g, e, u, __mul24(gd, gd), div);
         }
     }
-    env_finish(E, g, e);
+    env_finish(E, g, e, e.deepest + 1, &counters[3]);
     __syncthreads();
     env_write(E, plane + (size_t)x * div * div, (size_t)div, (unsigned)z, div * g / G, div * (g + 1) / G);
 }
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_x(const int* __restrict__ p
         for (int j = 0; j < EDT_PF; j++)
             if (k0 + j < khi) env_add(E, g, e, Uc[j], Gc[j], div);
     }
-    env_finish(E, g, e);
+    env_finish(E, g, e, e.deepest + 1, &counters[7]);
     __syncthreads();
     env_write(E, sq, xs, (unsigned)rowoff, div * g / G, div * (g + 1) / G);
 }
@@ -484,7 +492,8 @@ __global__ void k_edt_lookup(const int* __restrict__ sq, int div, float mnx, flo
 }  // namespace
 
 // Two sets of uint64 x 8 behind the occupancy bits, used by alternate builds: {occupied voxels, dropped
-// points, non-empty planes, -, overflow pass zy, overflow pass x, census ticket, -}
+// points, non-empty planes, deepest stack of pass zy, overflow pass zy, overflow pass x, census ticket,
+// deepest stack of pass x}
 static u64* edt_counter_set(const icpx_ctx* ctx, int set) {
     return ctx->edt_bits.as<u64>() + (size_t)ctx->div * ctx->div * ctx->edt_words + 8 * (set & 1);
 }
@@ -499,6 +508,19 @@ static size_t edt_spill_bytes(const icpx_ctx* ctx) {
         need = std::max(need, (size_t)levels * t->groups * ctx->div * ctx->div * sizeof(uint2));
     }
     return need;
+}
+
+// Shapes the LDS of the envelope passes for later builds from the deepest stacks the last build saw: if
+// they fit a workgroup's private levels at three workgroups per CU, every level is private and the pool
+// is dropped (reads and writes above the private levels cost several times more); otherwise the default
+// private levels plus pool stay. Shapes forced through the environment are left alone.
+static void edt_adapt(icpx_ctx* ctx, u64 deepest_zy, u64 deepest_x) {
+    if (ctx->edt_tune_fixed) return;
+    const EnvTune def{4, 28, 40};
+    const int cap_max = 33;   // 4 groups x 33 levels x 384 B + header = 52 KiB: three workgroups per CU
+    const u64 d[2] = {deepest_zy, deepest_x};
+    EnvTune* t[2] = {&ctx->edt_zy, &ctx->edt_x};
+    for (int k = 0; k < 2; k++) *t[k] = d[k] >= 1 && d[k] <= (u64)cap_max ? EnvTune{4, std::max((int)d[k], 8), 0} : def;
 }
 
 // Launch on the stream; with ev != NULL the dispatch carries the start / stop events of its stage, which
@@ -601,7 +623,7 @@ extern "C" int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, edt_counters(ctx), sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
         ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (counters[0] == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "EDT build: no target point falls inside the grid");
-        if (!counters[4] && !counters[5]) break;
+        if (!counters[4] && !counters[5]) { edt_adapt(ctx, counters[3], counters[7]); break; }
         // Some row's envelope did not fit the LDS levels and pool: give the passes a spill buffer and repeat
         // the build.
         if (attempt == 1) ICPX_FAIL(ctx, ICPX_EHIP, "EDT build: stack overflow persisted with a spill buffer");
