@@ -198,6 +198,8 @@ struct Env {
     __device__ __forceinline__ unsigned short& depth(int g) const { return *reinterpret_cast<unsigned short*>(lds + (g * 64 + lane) * 2); }
     __device__ __forceinline__ unsigned& table(int g) const { return *reinterpret_cast<unsigned*>(lds + G * 128 + (g * 64 + lane) * 4); }
     __device__ __forceinline__ unsigned* counter() const { return reinterpret_cast<unsigned*>(lds + G * 384); }
+    // winning stack at the last position of every part [G][64] u8 (in the padding behind the counter)
+    __device__ __forceinline__ unsigned char& winner(int g) const { return *reinterpret_cast<unsigned char*>(lds + G * 384 + 64 + g * 64 + lane); }
     // byte addresses of level 0 of group g for this lane
     __device__ __forceinline__ int wbase(int g) const { return off_w + g * cap * 256 + lane * 4; }
     __device__ __forceinline__ int tbase(int g) const { return off_t + g * cap * 128 + lane * 2; }
@@ -306,6 +308,7 @@ __device__ __forceinline__ void env_finish(const Env<G>& E, int g, EnvTop& e, in
 struct EnvCur {
     int lvl;                // level of the current entry
     unsigned cw; int ct;    // current entry
+    unsigned bw; int bt;    // entry one level below (whatever precedes the stack in LDS when lvl == 0: never used)
     int wb, tb;             // LDS byte addresses of level 0 of the stack
     unsigned tab;
 };
@@ -323,47 +326,108 @@ __device__ __forceinline__ void env_seek(const Env<G>& E, int j, EnvCur& c, int 
     }
     c.lvl = lo;
     E.load(j, c.wb, c.tb, c.tab, lo, c.cw, c.ct);
+    E.load(j, c.wb, c.tb, c.tab, lo - 1, c.bw, c.bt);
 }
 
-// Value of stack j's envelope at position p, then one level down if p was the first position of the
-// entry; the entry of the new level is read back every time, which keeps the step branch-free.
+// f(p) - p^2 of the entry under the cursor: a 24-bit multiply-add
+__device__ __forceinline__ int env_value(const EnvCur& c, int p) {
+    return (int)(c.cw >> ENV_VB) * (-2 * (p & 0x3ff)) + (int)(c.cw & ENV_VMASK);
+}
+
+// One level down if p was the first position of the current entry. The entry below is already in
+// registers; the one below that is read back every time (branch-free) and is not needed before the next
+// step of this cursor, so the LDS latency stays off the dependent chain.
 // HIGH: some lane's cursor may still be above the private levels.
 template <int G, bool HIGH>
-__device__ __forceinline__ int env_eval(const Env<G>& E, int j, EnvCur& c, int p) {
-    const int v = (int)(c.cw >> ENV_VB) * (-2 * (p & 0x3ff)) + (int)(c.cw & ENV_VMASK);   // f(p) - p^2; a 24-bit multiply-add
-    c.lvl -= p == c.ct ? 1 : 0;
-    if (HIGH) E.load(j, c.wb, c.tb, c.tab, c.lvl, c.cw, c.ct);
-    else { c.cw = E.W(c.wb, c.lvl); c.ct = E.T(c.tb, c.lvl); }
-    return v;
+__device__ __forceinline__ void env_step(const Env<G>& E, int j, EnvCur& c, int p) {
+    const bool down = p == c.ct;
+    c.cw = down ? c.bw : c.cw;
+    c.ct = down ? c.bt : c.ct;
+    c.lvl -= down ? 1 : 0;
+    if (HIGH) E.load(j, c.wb, c.tb, c.tab, c.lvl - 1, c.bw, c.bt);
+    else { c.bw = E.W(c.wb - 256, c.lvl); c.bt = E.T(c.tb - 128, c.lvl); }
 }
 
-// Writes positions [plo, phi) of this lane's row: out[p * stride + lane_off] = min over the G stacks.
-template <int G>
-__device__ __forceinline__ void env_write(const Env<G>& E, int* __restrict__ out, size_t stride, unsigned lane_off, int plo, int phi) {
-    if (phi <= plo) return;
-    EnvCur cur[G];
-#pragma unroll
-    for (int j = 0; j < G; j++) env_seek(E, j, cur[j], phi - 1);
-    int p = phi - 1;
+// Positions [plo, p] of this lane's row from stacks LO .. LO + N - 1 only.
+template <int G, int LO, int N>
+__device__ __forceinline__ void env_span(const Env<G>& E, EnvCur (&cur)[G], int* __restrict__ out, size_t stride, unsigned lane_off,
+                                         int plo, int p) {
     for (;;) {   // general steps while any cursor of the wave is above the private levels
         bool high = false;
 #pragma unroll
-        for (int j = 0; j < G; j++) high |= cur[j].lvl >= E.cap;
+        for (int j = LO; j < LO + N; j++) high |= cur[j].lvl >= E.cap;
         if (p < plo || !__any(high)) break;
         int v = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < G; j++)   // only the stacks that are still above pay for the general read-back
-            v = min(v, __any(cur[j].lvl >= E.cap) ? env_eval<G, true>(E, j, cur[j], p) : env_eval<G, false>(E, j, cur[j], p));
+        for (int j = LO; j < LO + N; j++) v = min(v, env_value(cur[j], p));
         if (E.active) (out + (size_t)p * stride)[lane_off] = v + p * p;
+#pragma unroll
+        for (int j = LO; j < LO + N; j++) {   // only the stacks that are still above pay for the general read-back
+            if (__any(cur[j].lvl >= E.cap)) env_step<G, true>(E, j, cur[j], p);
+            else env_step<G, false>(E, j, cur[j], p);
+        }
         p--;
     }
 #pragma unroll 2
     for (; p >= plo; p--) {
         int v = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < G; j++) v = min(v, env_eval<G, false>(E, j, cur[j], p));
+        for (int j = LO; j < LO + N; j++) v = min(v, env_value(cur[j], p));
         if (E.active) (out + (size_t)p * stride)[lane_off] = v + p * p;
+#pragma unroll
+        for (int j = LO; j < LO + N; j++) env_step<G, false>(E, j, cur[j], p);
     }
+}
+
+template <int G, int LO, int N>
+__device__ __forceinline__ void env_dispatch(int jlo, int n, const Env<G>& E, EnvCur (&cur)[G], int* __restrict__ out, size_t stride,
+                                             unsigned lane_off, int plo, int p) {
+    if constexpr (LO + N <= G) {
+        if (jlo == LO && n == N) { env_span<G, LO, N>(E, cur, out, stride, lane_off, plo, p); return; }
+        if constexpr (LO + N < G) env_dispatch<G, LO, N + 1>(jlo, n, E, cur, out, stride, lane_off, plo, p);
+        else if constexpr (LO + 1 < G) env_dispatch<G, LO + 1, 1>(jlo, n, E, cur, out, stride, lane_off, plo, p);
+    }
+}
+
+// Writes positions [plo, phi) of this lane's row: out[p * stride + lane_off] = min over the G stacks;
+// wave g of the workgroup handles part g of the positions. Called by all waves (contains a barrier).
+// Stack i holds sites left of those of stack j > i, so envelope_i(p) - envelope_j(p) grows with p and the
+// index of the stack that attains the minimum never decreases with p: the stacks that can matter inside
+// a part lie between a winner at the last position of the previous part (found by the previous wave) and
+// a winner at the part's own last position. The wave evaluates only the range of stacks that covers this
+// interval for all of its lanes (usually one or two of the G).
+template <int G>
+__device__ __forceinline__ void env_write(const Env<G>& E, int g, int* __restrict__ out, size_t stride, unsigned lane_off, int div) {
+    const int plo = div * g / G, phi = div * (g + 1) / G;
+    EnvCur cur[G];
+    int jlo = 0, jhi = G - 1;
+    if (G > 1) {
+        int vtop[G];
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            env_seek(E, j, cur[j], max(phi - 1, 0));
+            vtop[j] = env_value(cur[j], max(phi - 1, 0));
+        }
+        int mt = vtop[0];
+#pragma unroll
+        for (int j = 1; j < G; j++) mt = min(mt, vtop[j]);
+        int a = 0;                            // last winner at the top position of this part
+#pragma unroll
+        for (int j = 0; j < G; j++) { if (vtop[j] == mt) a = j; }
+        E.winner(g) = (unsigned char)a;
+        __syncthreads();
+        const int b = g > 0 ? min((int)E.winner(g - 1), a) : 0;
+        jhi = 0; jlo = G - 1;
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            if (__any(a == j)) jhi = j;
+            if (__any(b == G - 1 - j)) jlo = G - 1 - j;
+        }
+    } else {
+        env_seek(E, 0, cur[0], max(phi - 1, 0));
+    }
+    if (phi <= plo) return;
+    env_dispatch<G, 0, 1>(jlo, jhi - jlo + 1, E, cur, out, stride, lane_off, plo, phi - 1);
 }
 
 // LDS layout: header (depths, chunk tables, pool counter) padded so that reads two levels below level 0
@@ -432,7 +496,7 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict
     }
     env_finish(E, g, e, e.deepest + 1, &counters[3]);
     __syncthreads();
-    env_write(E, plane + (size_t)x * div * div, (size_t)div, (unsigned)z, div * g / G, div * (g + 1) / G);
+    env_write(E, g, plane + (size_t)x * div * div, (size_t)div, (unsigned)z, div);
 }
 
 // ---- pass x ---------------------------------------------------------------------------------------------
@@ -478,7 +542,7 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_x(const int* __restrict__ p
     }
     env_finish(E, g, e, e.deepest + 1, &counters[7]);
     __syncthreads();
-    env_write(E, sq, xs, (unsigned)rowoff, div * g / G, div * (g + 1) / G);
+    env_write(E, g, sq, xs, (unsigned)rowoff, div);
 }
 
 // ---- lookup (device function in icpx_edt_dev.h) ----
