@@ -63,6 +63,7 @@ struct icpx_ctx {
     // workgroups (12 waves) per CU; measured best on the 300^3 bunny grid among the shapes tried.
     EnvTune edt_zy{4, 28, 40}, edt_x{4, 28, 40};
     bool edt_tune_fixed = false;   // shapes came from the environment: do not adapt them to the data
+    bool edt_overflowed = false;   // a build needed levels beyond the private ones: use the kernels with pool / spill tiers
     DevBuf edt_bits;         // div*div*edt_words uint64 occupancy bits, then two sets of 8 uint64 counters (alternate builds)
     int edt_epoch = 0;       // counter set of the latest build
     DevBuf edt_rowlist;      // [x][chunk][k] 16-byte records of the non-empty rows of every plane (see k_edt_census)

@@ -182,7 +182,7 @@ constexpr unsigned ENV_VMASK = (1u << ENV_VB) - 1;
 constexpr int ENV_CHUNK = 8;        // levels per pool chunk
 constexpr int ENV_MAXCH = 4;        // chunks per stack
 
-template <int G>
+template <int G, bool POOL>
 struct Env {
     char* lds;
     int cap, nch, lane;
@@ -225,8 +225,10 @@ struct Env {
             w = v.x; t = (int)v.y;
         }
     }
+    // POOL == false: every level the scan keeps is private (the host picked cap from the deepest stack of
+    // an earlier build of the same data); a level beyond only raises the overflow flag.
     __device__ __forceinline__ void load(int g, int wb, int tb, unsigned tab, int level, unsigned& w, int& t) const {
-        if (level < cap) { w = W(wb, level); t = T(tb, level); }
+        if (!POOL || level < cap) { w = W(wb, level); t = T(tb, level); }
         else load_high(g, tab, level, w, t);
     }
     __device__ void store_high(int g, unsigned& tab, int level, unsigned w, int t) const {
@@ -244,7 +246,8 @@ struct Env {
     }
     __device__ __forceinline__ void store(int g, int wb, int tb, unsigned& tab, int level, unsigned w, int t) const {
         if (level < cap) { W(wb, level) = w; T(tb, level) = (unsigned short)t; }
-        else store_high(g, tab, level, w, t);
+        else if (POOL) store_high(g, tab, level, w, t);
+        else *ovf = 1;
     }
 };
 
@@ -259,8 +262,8 @@ struct EnvTop {
     int deepest;            // largest q so far
 };
 
-template <int G>
-__device__ __forceinline__ void env_init(const Env<G>& E, int g, EnvTop& e) {
+template <int G, bool POOL>
+__device__ __forceinline__ void env_init(const Env<G, POOL>& E, int g, EnvTop& e) {
     e = EnvTop{-1, 0, 0, 0, 0u, 0, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu, -1};
 }
 
@@ -270,8 +273,8 @@ __device__ __forceinline__ void env_init(const Env<G>& E, int g, EnvTop& e) {
 // f(p) = p^2 - 2 p s + a, so "new lower than top at t" is 2 t (u - s) + (a_top - a_u) > 0 and the
 // crossing is (a_u - a_top) / (2 (u - s)); entries carry a instead of v. Reads below the bottom of a
 // stack return whatever precedes it in LDS and are never used.
-template <int G>
-__device__ __forceinline__ void env_add(const Env<G>& E, int g, EnvTop& e, int u, int v, int div) {
+template <int G, bool POOL>
+__device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e, int u, int v, int div) {
     const int au = (u & 0x3ff) * (u & 0x3ff) + v;
     int d, dd;
     for (;;) {
@@ -295,8 +298,8 @@ __device__ __forceinline__ void env_add(const Env<G>& E, int g, EnvTop& e, int u
 // Ends the scan of group g: publishes depth and chunk table (a group without sites gets one entry that
 // loses against every real one) and reports the deepest level count any stack of the wave reached, which
 // the host uses to size the private levels of later builds.
-template <int G>
-__device__ __forceinline__ void env_finish(const Env<G>& E, int g, EnvTop& e, int deepest, u64* max_depth) {
+template <int G, bool POOL>
+__device__ __forceinline__ void env_finish(const Env<G, POOL>& E, int g, EnvTop& e, int deepest, u64* max_depth) {
     for (int o = 32; o; o >>= 1) deepest = max(deepest, __shfl_xor(deepest, o));
     if (E.lane == 0 && (u64)deepest > *(volatile u64*)max_depth) atomicMax(max_depth, (u64)deepest);
     if (e.q < 0) { e.q = 0; E.store(g, e.wb, e.tb, e.tab, 0, ENV_VMASK, 0); }
@@ -314,8 +317,8 @@ struct EnvCur {
 };
 
 // Positions the cursor on the entry of group j that owns position p (largest level whose start is <= p).
-template <int G>
-__device__ __forceinline__ void env_seek(const Env<G>& E, int j, EnvCur& c, int p) {
+template <int G, bool POOL>
+__device__ __forceinline__ void env_seek(const Env<G, POOL>& E, int j, EnvCur& c, int p) {
     c.wb = E.wbase(j); c.tb = E.tbase(j); c.tab = E.table(j);
     int lo = 0, hi = E.depth(j);
     while (lo < hi) {
@@ -338,8 +341,8 @@ __device__ __forceinline__ int env_value(const EnvCur& c, int p) {
 // registers; the one below that is read back every time (branch-free) and is not needed before the next
 // step of this cursor, so the LDS latency stays off the dependent chain.
 // HIGH: some lane's cursor may still be above the private levels.
-template <int G, bool HIGH>
-__device__ __forceinline__ void env_step(const Env<G>& E, int j, EnvCur& c, int p) {
+template <int G, bool POOL, bool HIGH>
+__device__ __forceinline__ void env_step(const Env<G, POOL>& E, int j, EnvCur& c, int p) {
     const bool down = p == c.ct;
     c.cw = down ? c.bw : c.cw;
     c.ct = down ? c.bt : c.ct;
@@ -349,10 +352,10 @@ __device__ __forceinline__ void env_step(const Env<G>& E, int j, EnvCur& c, int 
 }
 
 // Positions [plo, p] of this lane's row from stacks LO .. LO + N - 1 only.
-template <int G, int LO, int N>
-__device__ __forceinline__ void env_span(const Env<G>& E, EnvCur (&cur)[G], int* __restrict__ out, size_t stride, unsigned lane_off,
+template <int G, bool POOL, int LO, int N>
+__device__ __forceinline__ void env_span(const Env<G, POOL>& E, EnvCur (&cur)[G], int* __restrict__ out, size_t stride, unsigned lane_off,
                                          int plo, int p) {
-    for (;;) {   // general steps while any cursor of the wave is above the private levels
+    for (; POOL;) {   // general steps while any cursor of the wave is above the private levels
         bool high = false;
 #pragma unroll
         for (int j = LO; j < LO + N; j++) high |= cur[j].lvl >= E.cap;
@@ -363,8 +366,8 @@ __device__ __forceinline__ void env_span(const Env<G>& E, EnvCur (&cur)[G], int*
         if (E.active) (out + (size_t)p * stride)[lane_off] = v + p * p;
 #pragma unroll
         for (int j = LO; j < LO + N; j++) {   // only the stacks that are still above pay for the general read-back
-            if (__any(cur[j].lvl >= E.cap)) env_step<G, true>(E, j, cur[j], p);
-            else env_step<G, false>(E, j, cur[j], p);
+            if (__any(cur[j].lvl >= E.cap)) env_step<G, POOL, true>(E, j, cur[j], p);
+            else env_step<G, POOL, false>(E, j, cur[j], p);
         }
         p--;
     }
@@ -375,17 +378,17 @@ __device__ __forceinline__ void env_span(const Env<G>& E, EnvCur (&cur)[G], int*
         for (int j = LO; j < LO + N; j++) v = min(v, env_value(cur[j], p));
         if (E.active) (out + (size_t)p * stride)[lane_off] = v + p * p;
 #pragma unroll
-        for (int j = LO; j < LO + N; j++) env_step<G, false>(E, j, cur[j], p);
+        for (int j = LO; j < LO + N; j++) env_step<G, POOL, false>(E, j, cur[j], p);
     }
 }
 
-template <int G, int LO, int N>
-__device__ __forceinline__ void env_dispatch(int jlo, int n, const Env<G>& E, EnvCur (&cur)[G], int* __restrict__ out, size_t stride,
+template <int G, bool POOL, int LO, int N>
+__device__ __forceinline__ void env_dispatch(int jlo, int n, const Env<G, POOL>& E, EnvCur (&cur)[G], int* __restrict__ out, size_t stride,
                                              unsigned lane_off, int plo, int p) {
     if constexpr (LO + N <= G) {
-        if (jlo == LO && n == N) { env_span<G, LO, N>(E, cur, out, stride, lane_off, plo, p); return; }
-        if constexpr (LO + N < G) env_dispatch<G, LO, N + 1>(jlo, n, E, cur, out, stride, lane_off, plo, p);
-        else if constexpr (LO + 1 < G) env_dispatch<G, LO + 1, 1>(jlo, n, E, cur, out, stride, lane_off, plo, p);
+        if (jlo == LO && n == N) { env_span<G, POOL, LO, N>(E, cur, out, stride, lane_off, plo, p); return; }
+        if constexpr (LO + N < G) env_dispatch<G, POOL, LO, N + 1>(jlo, n, E, cur, out, stride, lane_off, plo, p);
+        else if constexpr (LO + 1 < G) env_dispatch<G, POOL, LO + 1, 1>(jlo, n, E, cur, out, stride, lane_off, plo, p);
     }
 }
 
@@ -396,8 +399,8 @@ __device__ __forceinline__ void env_dispatch(int jlo, int n, const Env<G>& E, En
 // a part lie between a winner at the last position of the previous part (found by the previous wave) and
 // a winner at the part's own last position. The wave evaluates only the range of stacks that covers this
 // interval for all of its lanes (usually one or two of the G).
-template <int G>
-__device__ __forceinline__ void env_write(const Env<G>& E, int g, int* __restrict__ out, size_t stride, unsigned lane_off, int div) {
+template <int G, bool POOL>
+__device__ __forceinline__ void env_write(const Env<G, POOL>& E, int g, int* __restrict__ out, size_t stride, unsigned lane_off, int div) {
     const int plo = div * g / G, phi = div * (g + 1) / G;
     EnvCur cur[G];
     int jlo = 0, jhi = G - 1;
@@ -427,7 +430,7 @@ __device__ __forceinline__ void env_write(const Env<G>& E, int g, int* __restric
         env_seek(E, 0, cur[0], max(phi - 1, 0));
     }
     if (phi <= plo) return;
-    env_dispatch<G, 0, 1>(jlo, jhi - jlo + 1, E, cur, out, stride, lane_off, plo, phi - 1);
+    env_dispatch<G, POOL, 0, 1>(jlo, jhi - jlo + 1, E, cur, out, stride, lane_off, plo, phi - 1);
 }
 
 // LDS layout: header (depths, chunk tables, pool counter) padded so that reads two levels below level 0
@@ -435,10 +438,10 @@ __device__ __forceinline__ void env_write(const Env<G>& E, int g, int* __restric
 static inline int env_off_w(int G) { return G * 384 + 512; }
 static size_t env_lds_bytes(int G, int cap, int nch) { return (size_t)env_off_w(G) + (size_t)G * cap * 384 + (size_t)nch * ENV_CHUNK * 6; }
 
-template <int G>
-__device__ __forceinline__ Env<G> env_setup(unsigned* lds, int cap, int nch, int lane, uint2* sp, int div, size_t rows, size_t row,
+template <int G, bool POOL>
+__device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int cap, int nch, int lane, uint2* sp, int div, size_t rows, size_t row,
                                             u64* ovf, bool active) {
-    Env<G> E;
+    Env<G, POOL> E;
     E.lds = reinterpret_cast<char*>(lds);
     E.cap = cap; E.nch = nch; E.lane = lane;
     E.off_w = G * 384 + 512;
@@ -457,7 +460,7 @@ __device__ __forceinline__ Env<G> env_setup(unsigned* lds, int cap, int nch, int
 // Workgroup = plane x, 64 consecutive z; lane = z. Sites are the plane's non-empty rows y; their records
 // are fetched 64 at a time (lane j holds record j of the wave's site range, one coalesced load, the next
 // block prefetched) and broadcast with v_readlane as the scan reaches them. Value = (distance along z)^2.
-template <int G>
+template <int G, bool POOL>
 __global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict__ recs, const int* __restrict__ rowcnt,
                                                         int* __restrict__ plane, uint2* __restrict__ spill_buf, u64* __restrict__ counters,
                                                         int div, int W, int cap, int nch) {
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict
     const bool active = c * 64 + lane < div;
     const int z = active ? c * 64 + lane : div - 1;
     const int zl = z & 63;
-    const Env<G> E = env_setup<G>(lds, cap, nch, lane, spill_buf, div, (size_t)div * div, (size_t)x * div + z, &counters[4], active);
+    const Env<G, POOL> E = env_setup<G, POOL>(lds, cap, nch, lane, spill_buf, div, (size_t)div * div, (size_t)x * div + z, &counters[4], active);
 
     const int klo = cnt * g / G, khi = cnt * (g + 1) / G;
     const int4* rr4 = reinterpret_cast<const int4*>(recs + ((size_t)x * W + c) * div);
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict
 // per plane).
 constexpr int EDT_PF = 8;
 
-template <int G>
+template <int G, bool POOL>
 __global__ __launch_bounds__(64 * G) void k_edt_pass_x(const int* __restrict__ plane, const int* __restrict__ planelist,
                                                        u64* __restrict__ counters, int* __restrict__ sq, uint2* __restrict__ spill_buf,
                                                        int div, int nchunk, int cap, int nch) {
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_x(const int* __restrict__ p
     const int np = (int)counters[2];
     const size_t xs = (size_t)div * div;                  // elements between consecutive x
     const int rowoff = y * div + z;
-    const Env<G> E = env_setup<G>(lds, cap, nch, lane, spill_buf, div, xs, (size_t)rowoff, &counters[5], active);
+    const Env<G, POOL> E = env_setup<G, POOL>(lds, cap, nch, lane, spill_buf, div, xs, (size_t)rowoff, &counters[5], active);
 
     const int klo = np * g / G, khi = np * (g + 1) / G;
     EnvTop e;
@@ -584,7 +587,13 @@ static void edt_adapt(icpx_ctx* ctx, u64 deepest_zy, u64 deepest_x) {
     const int cap_max = 33;   // 4 groups x 33 levels x 384 B + header = 52 KiB: three workgroups per CU
     const u64 d[2] = {deepest_zy, deepest_x};
     EnvTune* t[2] = {&ctx->edt_zy, &ctx->edt_x};
-    for (int k = 0; k < 2; k++) *t[k] = d[k] >= 1 && d[k] <= (u64)cap_max ? EnvTune{4, std::max((int)d[k], 8), 0} : def;
+    bool fits = true;
+    for (int k = 0; k < 2; k++) {
+        const bool f = d[k] >= 1 && d[k] <= (u64)cap_max;
+        *t[k] = f ? EnvTune{4, std::max((int)d[k], 8), 0} : def;
+        fits = fits && f;
+    }
+    if (fits) ctx->edt_overflowed = false;
 }
 
 // Launch on the stream; with ev != NULL the dispatch carries the start / stop events of its stage, which
@@ -614,13 +623,17 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
                ctx->edt_planelist.as<int>());
     {
         const int G = ctx->edt_zy.groups, cap = ctx->edt_zy.cap, nch = ctx->edt_zy.chunks;
-        auto zy = G == 1 ? k_edt_pass_zy<1> : G == 2 ? k_edt_pass_zy<2> : G == 3 ? k_edt_pass_zy<3> : k_edt_pass_zy<4>;
+        const bool pool = nch > 0 || ctx->edt_overflowed;
+        auto zy = pool ? (G == 1 ? k_edt_pass_zy<1, true> : G == 2 ? k_edt_pass_zy<2, true> : G == 3 ? k_edt_pass_zy<3, true> : k_edt_pass_zy<4, true>)
+                       : (G == 1 ? k_edt_pass_zy<1, false> : G == 2 ? k_edt_pass_zy<2, false> : G == 3 ? k_edt_pass_zy<3, false> : k_edt_pass_zy<4, false>);
         edt_launch(zy, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ev, 2, (const RowRec*)ctx->edt_rowlist.as<RowRec>(),
                    (const int*)ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, counters, div, W, cap, nch);
     }
     {
         const int G = ctx->edt_x.groups, cap = ctx->edt_x.cap, nch = ctx->edt_x.chunks;
-        auto px = G == 1 ? k_edt_pass_x<1> : G == 2 ? k_edt_pass_x<2> : G == 3 ? k_edt_pass_x<3> : k_edt_pass_x<4>;
+        const bool pool = nch > 0 || ctx->edt_overflowed;
+        auto px = pool ? (G == 1 ? k_edt_pass_x<1, true> : G == 2 ? k_edt_pass_x<2, true> : G == 3 ? k_edt_pass_x<3, true> : k_edt_pass_x<4, true>)
+                       : (G == 1 ? k_edt_pass_x<1, false> : G == 2 ? k_edt_pass_x<2, false> : G == 3 ? k_edt_pass_x<3, false> : k_edt_pass_x<4, false>);
         edt_launch(px, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ev, 3, (const int*)ctx->edt_plane.as<int>(),
                    (const int*)ctx->edt_planelist.as<int>(), counters, ctx->edt_sq.as<int>(), spill, div, nchunk, cap, nch);
     }
@@ -688,6 +701,7 @@ extern "C" int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[
         ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (counters[0] == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "EDT build: no target point falls inside the grid");
         if (!counters[4] && !counters[5]) { edt_adapt(ctx, counters[3], counters[7]); break; }
+        ctx->edt_overflowed = true;   // from now on the kernels with the pool / spill tiers, until a build fits
         // Some row's envelope did not fit the LDS levels and pool: give the passes a spill buffer and repeat
         // the build.
         if (attempt == 1) ICPX_FAIL(ctx, ICPX_EHIP, "EDT build: stack overflow persisted with a spill buffer");
