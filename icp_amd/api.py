@@ -110,6 +110,13 @@ class Context:
                                          idx.ctypes.data_as(C.c_void_p) if want_idx else None, HOST))
         return (sums, idx) if want_idx else sums
 
+    def icp_step_trimmed(self, T, keep):
+        """Sums of icp_step over the `keep` pairs with the smallest squared distances."""
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        sums = np.empty(NSUMS, np.float64)
+        self._ck(self._lib.icpx_icp_step_trimmed(self._h, T.ctypes.data_as(C.c_void_p), int(keep), sums.ctypes.data_as(C.c_void_p)))
+        return sums
+
     def icp_step_async(self, T, sums_dev):
         T = np.ascontiguousarray(T, np.float64).reshape(16)
         p, where = _ptr(sums_dev, np.float64)

@@ -210,6 +210,79 @@ const std::vector<float>& LDT::grid() {
     return g_;
 }
 
+// ---- ICP3D -------------------------------------------------------------------------------------------------
+
+ICP3D::ICP3D(DevicePtr d) : err_diff_def(0.000001), max_iter_def(10000), trim_fraction(0), do_trim(true), dev(d ? d : std::make_shared<Device>(0)) {}
+
+static PointCloudTPtr cloud_from_doubles(const double* xyz, size_t n) {
+    auto c = std::make_shared<PointCloudT>();
+    c->points.resize(n);
+    for (size_t i = 0; i < n; i++) c->points[i] = Point3f((float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2]);
+    return c;
+}
+
+void ICP3D::Build(const double* model, size_t n) {
+    if (!model || n == 0) throw IcpxFailure(ICPX_EINVAL, "ICP3D::Build: empty model");
+    model_ = cloud_from_doubles(model, n);
+    ensure_target_on(dev, model_);
+}
+
+double ICP3D::Run(const double* data, size_t n, Matrix3d& R, Vector3d& t) { return Run(data, n, R, t, max_iter_def, err_diff_def); }
+double ICP3D::Run(const double* data, size_t n, Matrix3d& R, Vector3d& t, size_t max_iter) { return Run(data, n, R, t, max_iter, err_diff_def); }
+double ICP3D::Run(const double* data, size_t n, Matrix3d& R, Vector3d& t, double err_diff) { return Run(data, n, R, t, max_iter_def, err_diff); }
+
+double ICP3D::Run(const double* data, size_t n, Matrix3d& R, Vector3d& t, size_t max_iter, double err_diff) {
+    if (!model_) throw IcpxFailure(ICPX_ESTATE, "ICP3D::Run before Build");
+    if (!data || n == 0) throw IcpxFailure(ICPX_EINVAL, "ICP3D::Run: empty data");
+    ensure_target_on(dev, model_);
+    if (!data_ || data_key_.size() != 3 * n || std::memcmp(data_key_.data(), data, 3 * n * sizeof(double)) != 0) {
+        data_ = cloud_from_doubles(data, n);
+        data_key_.assign(data, data + 3 * n);
+    }
+    dev->check(icpx_set_source(dev->ctx(), &data_->points[0].x, n, sizeof(Point3f), ICPX_HOST));
+    const size_t num = do_trim ? (size_t)(int)((double)n * (1 - trim_fraction)) : n;   // :189-196
+    // The means are set to zero once and then accumulate over the iterations (mu += ... at :244-252,
+    // mu = mu / n at :262-263, always by n): reproduced.
+    double mu_m[3] = {0, 0, 0}, mu_d[3] = {0, 0, 0};
+    double err = -1, err_new = 0;
+    iterations = 0;
+    for (size_t iter = 0; iter < max_iter; iter++) {
+        iterations = iter + 1;
+        double T[16] = {R(0, 0), R(0, 1), R(0, 2), t[0], R(1, 0), R(1, 1), R(1, 2), t[1], R(2, 0), R(2, 1), R(2, 2), t[2], 0, 0, 0, 1};
+        double sums[ICPX_NSUMS];
+        dev->check(icpx_icp_step_trimmed(dev->ctx(), T, num, sums));
+        for (int c = 0; c < 3; c++) { mu_d[c] += sums[c]; mu_m[c] += sums[3 + c]; }
+        err_new = sums[15];
+        if (err > 0 && err - err_new < err_diff * (double)num) break;   // :257
+        err = err_new;
+        for (int c = 0; c < 3; c++) { mu_m[c] /= (double)n; mu_d[c] /= (double)n; }
+        // H = sum (p - mu_d)(q - mu_m)^T over the kept pairs (:264-268), from the sums
+        Matrix3d H;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++)
+                H(r, c) = sums[6 + 3 * r + c] - mu_d[r] * sums[3 + c] - sums[r] * mu_m[c] + (double)num * mu_d[r] * mu_m[c];
+        Matrix3d U, V;
+        double w[3];
+        svd3(H, U, w, V);
+        Matrix3d R_;
+        auto make = [&](double d) {
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) R_(i, j) = V(i, 0) * U(j, 0) + V(i, 1) * U(j, 1) + d * V(i, 2) * U(j, 2);
+        };
+        make(1.0);
+        make(det3(R_));   // R_ = V diag(1, 1, det(V U^T)) U^T (:271-285)
+        double t_[3], Rn[9], tn[3];
+        for (int r = 0; r < 3; r++) t_[r] = mu_m[r] - (R_(r, 0) * mu_d[0] + R_(r, 1) * mu_d[1] + R_(r, 2) * mu_d[2]);
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) Rn[3 * r + c] = R_(r, 0) * R(0, c) + R_(r, 1) * R(1, c) + R_(r, 2) * R(2, c);
+            tn[r] = (R_(r, 0) * t[0] + R_(r, 1) * t[1] + R_(r, 2) * t[2]) + t_[r];
+        }
+        for (int k = 0; k < 9; k++) R.m[k] = Rn[k];
+        for (int r = 0; r < 3; r++) t[r] = tn[r];
+    }
+    return err_new;
+}
+
 // ---- SingleThreadIcp -----------------------------------------------------------------------------------------
 
 SingleThreadIcp::SingleThreadIcp(PointCloudTPtr _s, PointCloudTPtr _t, int _iter, DevicePtr d)
@@ -748,6 +821,30 @@ int icpxh_icp_registration(void* p, const double* guess16, double* T_out16, doub
         if (mse) for (int k = 0; k < it; k++) mse[k] = h->icp->mse_trace[k];
         if (resN3) std::memcpy(resN3, r.resN3.data.data(), r.resN3.data.size() * sizeof(double));
         if (idx_last) std::memcpy(idx_last, h->icp->Neighbour.pointsPARA.data(), sizeof(int32_t) * h->icp->Nd);
+    });
+}
+
+// ---- ICP3D
+struct HIcp3d { DevicePtr dev; std::unique_ptr<ICP3D> icp; };
+void* icpxh_icp3d_new(int device, const double* model, size_t m) {
+    HIcp3d* h = new HIcp3d;
+    if (guard([&] { h->dev = std::make_shared<Device>(device); h->icp.reset(new ICP3D(h->dev)); h->icp->Build(model, m); })) { delete h; return nullptr; }
+    return h;
+}
+void icpxh_icp3d_free(void* p) { delete (HIcp3d*)p; }
+// R9 / t3 in-out, row-major; do_trim / trim_fraction are the public fields of the class. Returns the error through *err.
+int icpxh_icp3d_run(void* p, const double* data, size_t n, double* R9, double* t3, size_t max_iter, double err_diff, int do_trim,
+                    double trim_fraction, double* err, size_t* iterations) {
+    return guard([&] {
+        HIcp3d* h = (HIcp3d*)p;
+        h->icp->do_trim = do_trim != 0; h->icp->trim_fraction = trim_fraction;
+        Matrix3d R; Vector3d t;
+        std::memcpy(R.m, R9, sizeof R.m);
+        for (int i = 0; i < 3; i++) t[i] = t3[i];
+        *err = h->icp->Run(data, n, R, t, max_iter, err_diff);
+        std::memcpy(R9, R.m, sizeof R.m);
+        for (int i = 0; i < 3; i++) t3[i] = t[i];
+        if (iterations) *iterations = h->icp->iterations;
     });
 }
 

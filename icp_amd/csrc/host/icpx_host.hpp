@@ -176,6 +176,30 @@ private:
     void ensure_target();
 };
 
+// The ICP of the original Go-ICP code base that the reference carries but does not call
+// (src/jly_icp3d.cpp:18-60, :181-295): nanoflann NN, optional trimming to the best (1 - trim_fraction) of
+// the pairs, stop when the summed squared error improves by less than err_diff per kept pair.
+// T = double only; the clouds are held as float32 on the GPU, so coordinates must be float-representable
+// for parity with the reference (they are for every PLY it ships).
+class ICP3D {
+public:
+    explicit ICP3D(DevicePtr dev = nullptr);
+    void Build(const double* model, size_t n);                                       // :130-154
+    double Run(const double* data, size_t n, Matrix3d& R, Vector3d& t);              // :162-166
+    double Run(const double* data, size_t n, Matrix3d& R, Vector3d& t, size_t max_iter);
+    double Run(const double* data, size_t n, Matrix3d& R, Vector3d& t, double err_diff);
+    double Run(const double* data, size_t n, Matrix3d& R, Vector3d& t, size_t max_iter, double err_diff);   // :181-295
+    double err_diff_def;      // 0.000001
+    size_t max_iter_def;      // 10000
+    double trim_fraction;     // 0
+    bool do_trim;             // true
+    size_t iterations = 0;    // passes of the last Run, the one that met the stop test included
+    DevicePtr dev;
+private:
+    PointCloudTPtr model_, data_;
+    std::vector<double> data_key_;
+};
+
 struct RotNode {            // src/GoIcp.cpp:25-33
     float a, b, c, w;
     double lb, ub;

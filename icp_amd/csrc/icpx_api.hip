@@ -88,7 +88,7 @@ extern "C" void icpx_destroy(icpx_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->tgt_xyz, &ctx->cell_range, &ctx->pyr_flags, &ctx->pyr_tab, &ctx->sorted_pts, &ctx->sort_keys_a, &ctx->sort_keys_b,
                       &ctx->sort_vals_a, &ctx->sort_vals_b, &ctx->sort_tmp, &ctx->src_pts, &ctx->partials, &ctx->sums,
                       &ctx->scratch_q, &ctx->scratch_idx, &ctx->scratch_d2, &ctx->scratch_f, &ctx->edt_bits,
-                      &ctx->edt_rowlist, &ctx->edt_rowcnt, &ctx->edt_planelist, &ctx->edt_counters, &ctx->edt_spill, &ctx->edt_plane,
+                      &ctx->edt_rowlist, &ctx->edt_rowcnt, &ctx->edt_planelist, &ctx->edt_counters, &ctx->trim_keys_a, &ctx->trim_keys_b, &ctx->trim_vals_a, &ctx->trim_vals_b, &ctx->trim_p, &ctx->trim_idx, &ctx->edt_spill, &ctx->edt_plane,
                       &ctx->edt_sq, &ctx->data_pts, &ctx->maxrot, &ctx->bnb_items, &ctx->bnb_partials, &ctx->bnb_out,
                       &ctx->bnb_mindis};
     for (DevBuf* b : bufs)
@@ -220,6 +220,16 @@ int icpx_sort_pairs(icpx_ctx* ctx, size_t n, unsigned end_bit) {
     ICPX_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, ka, kb, va, vb, n, 0, end_bit, ctx->stream));
     ICPX_TRY(icpx_reserve(ctx, ctx->sort_tmp, tmp));
     ICPX_CHECK_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, ka, kb, va, vb, n, 0, end_bit, ctx->stream));
+    return ICPX_OK;
+}
+
+// Stable sort of (64-bit keys, 32-bit values), caller-provided double buffers, on the context stream.
+int icpx_sort_pairs64(icpx_ctx* ctx, size_t n, const unsigned long long* keys_in, unsigned long long* keys_out, const unsigned* vals_in,
+                      unsigned* vals_out) {
+    size_t tmp = 0;
+    ICPX_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, n, 0, 64, ctx->stream));
+    ICPX_TRY(icpx_reserve(ctx, ctx->sort_tmp, tmp));
+    ICPX_CHECK_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, keys_in, keys_out, vals_in, vals_out, n, 0, 64, ctx->stream));
     return ICPX_OK;
 }
 

@@ -51,6 +51,9 @@ struct icpx_ctx {
     DevBuf partials;         // per-block partial sums
     DevBuf sums;             // ICPX_NSUMS doubles
     DevBuf scratch_q, scratch_idx, scratch_d2, scratch_f;   // staging for host-pointer calls
+    // trimmed ICP step, all indexed by the caller's source index: squared distances as sort keys, iota
+    // values, transformed points (3 doubles), correspondences
+    DevBuf trim_keys_a, trim_keys_b, trim_vals_a, trim_vals_b, trim_p, trim_idx;
 
     // ---- EDT ---------------------------------------------------------------------------------------
     bool edt_ready = false;

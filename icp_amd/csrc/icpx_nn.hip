@@ -16,6 +16,8 @@
 #include <cmath>
 
 int icpx_sort_pairs(icpx_ctx* ctx, size_t n, unsigned end_bit);
+int icpx_sort_pairs64(icpx_ctx* ctx, size_t n, const unsigned long long* keys_in, unsigned long long* keys_out, const unsigned* vals_in,
+                      unsigned* vals_out);
 int icpx_sort_reserve(icpx_ctx* ctx, size_t n);
 
 namespace {
@@ -266,6 +268,70 @@ __global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __re
         partials[(size_t)blockIdx.x * ICPX_NSUMS + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
+// Trimmed ICP pass, first half: p = T * [src;1] and its nearest target point for every source point, stored
+// under the caller's source index o: the squared distance as a sort key (the bits of a non-negative double
+// order like the value), o itself as the sort value, p and the correspondence.
+__global__ __launch_bounds__(256) void k_icp_pairs(GridView g, const float4* __restrict__ src, size_t n, Mat34 T,
+                                                   unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
+                                                   double* __restrict__ pbuf, int* __restrict__ idx) {
+    __shared__ unsigned stk[NN_LEVELS * 256];
+    __shared__ unsigned s_loff[MAXLEV];
+    if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 s = src[i];
+    double p[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        double a = 0.0;
+        a += T.m[4 * r + 0] * (double)s.x;
+        a += T.m[4 * r + 1] * (double)s.y;
+        a += T.m[4 * r + 2] * (double)s.z;
+        a += T.m[4 * r + 3];
+        p[r] = a;
+    }
+    const Best b = nn_search(g, p[0], p[1], p[2], stk + threadIdx.x, 256, s_loff);
+    const size_t o = (size_t)__float_as_int(s.w);
+    keys[o] = (unsigned long long)__double_as_longlong(b.d2);
+    vals[o] = (unsigned)o;
+    pbuf[3 * o] = p[0]; pbuf[3 * o + 1] = p[1]; pbuf[3 * o + 2] = p[2];
+    idx[o] = b.idx;
+}
+
+// Second half: block-partial sums {p, q, p q^T, |p-q|^2} over the `keep` pairs with the smallest squared
+// distances (order[0 .. keep) from the stable sort: ties go to the lower source index).
+__global__ __launch_bounds__(256) void k_icp_trim_sums(const unsigned* __restrict__ order, const unsigned long long* __restrict__ keys_sorted,
+                                                       size_t keep, const double* __restrict__ pbuf, const int* __restrict__ idx,
+                                                       const float* __restrict__ tgt_xyz, double* __restrict__ partials) {
+    double acc[ICPX_NSUMS];
+#pragma unroll
+    for (int k = 0; k < ICPX_NSUMS; k++) acc[k] = 0.0;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < keep; r += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = order[r];
+        const double p0 = pbuf[3 * o], p1 = pbuf[3 * o + 1], p2 = pbuf[3 * o + 2];
+        const size_t j = (size_t)idx[o];
+        const double q0 = (double)tgt_xyz[3 * j], q1 = (double)tgt_xyz[3 * j + 1], q2 = (double)tgt_xyz[3 * j + 2];
+        acc[0] += p0; acc[1] += p1; acc[2] += p2;
+        acc[3] += q0; acc[4] += q1; acc[5] += q2;
+        acc[6] += p0 * q0; acc[7] += p0 * q1; acc[8] += p0 * q2;
+        acc[9] += p1 * q0; acc[10] += p1 * q1; acc[11] += p1 * q2;
+        acc[12] += p2 * q0; acc[13] += p2 * q1; acc[14] += p2 * q2;
+        acc[15] += __longlong_as_double((long long)keys_sorted[r]);
+    }
+    __shared__ double sm[4][ICPX_NSUMS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < ICPX_NSUMS; k++) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) sm[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICPX_NSUMS)
+        partials[(size_t)blockIdx.x * ICPX_NSUMS + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
 // Fixed-order final reduction of the block partials: thread t sums component t%16 of blocks t/16, t/16+64, ...
 __global__ __launch_bounds__(1024) void k_reduce_sums(const double* __restrict__ partials, int nblocks, double* __restrict__ sums) {
     __shared__ double sm[1024];
@@ -473,6 +539,42 @@ extern "C" int icpx_icp_step(icpx_ctx* ctx, const double T[16], double sums[ICPX
     ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sums, ctx->sums.p, ICPX_NSUMS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (idx_opt && idx_where != ICPX_DEVICE)
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(idx_opt, didx, ctx->ns * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+extern "C" int icpx_icp_step_trimmed(icpx_ctx* ctx, const double T[16], uint64_t keep, double sums[ICPX_NSUMS]) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!sums) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_step_trimmed: sums is NULL");
+    if (!ctx->grid_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_step_trimmed: no target cloud (call icpx_set_target first)");
+    if (ctx->ns == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_step_trimmed: no source cloud (call icpx_set_source first)");
+    if (!T) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_step_trimmed: T is NULL");
+    if (keep > ctx->ns) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_step_trimmed: keep exceeds the number of source points");
+    ICPX_TRY(icpx_bind(ctx));
+    const size_t n = ctx->ns;
+    ICPX_TRY(icpx_reserve(ctx, ctx->sums, ICPX_NSUMS * sizeof(double)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->trim_keys_a, n * 8));
+    ICPX_TRY(icpx_reserve(ctx, ctx->trim_keys_b, n * 8));
+    ICPX_TRY(icpx_reserve(ctx, ctx->trim_vals_a, n * 4));
+    ICPX_TRY(icpx_reserve(ctx, ctx->trim_vals_b, n * 4));
+    ICPX_TRY(icpx_reserve(ctx, ctx->trim_p, n * 3 * sizeof(double)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->trim_idx, n * sizeof(int)));
+    const int blocks = (int)std::min<size_t>((std::max<size_t>(keep, 1) + 255) / 256, (size_t)ctx->num_cus * 32);
+    ICPX_TRY(icpx_reserve(ctx, ctx->partials, (size_t)blocks * ICPX_NSUMS * sizeof(double)));
+    Mat34 M;
+    for (int k = 0; k < 12; k++) M.m[k] = T[k];
+    hipLaunchKernelGGL(k_icp_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, view_of(ctx), ctx->src_pts.as<float4>(), n, M,
+                       ctx->trim_keys_a.as<unsigned long long>(), ctx->trim_vals_a.as<unsigned>(), ctx->trim_p.as<double>(),
+                       ctx->trim_idx.as<int>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_icp_pairs"));
+    ICPX_TRY(icpx_sort_pairs64(ctx, n, ctx->trim_keys_a.as<unsigned long long>(), ctx->trim_keys_b.as<unsigned long long>(),
+                               ctx->trim_vals_a.as<unsigned>(), ctx->trim_vals_b.as<unsigned>()));
+    hipLaunchKernelGGL(k_icp_trim_sums, dim3(blocks), dim3(256), 0, ctx->stream, ctx->trim_vals_b.as<unsigned>(),
+                       ctx->trim_keys_b.as<unsigned long long>(), (size_t)keep, ctx->trim_p.as<double>(), ctx->trim_idx.as<int>(),
+                       ctx->tgt_xyz.as<float>(), ctx->partials.as<double>());
+    hipLaunchKernelGGL(k_reduce_sums, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, ctx->sums.as<double>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_icp_trim_sums"));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sums, ctx->sums.p, ICPX_NSUMS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICPX_OK;
 }

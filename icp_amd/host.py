@@ -17,7 +17,7 @@ def _lib():
     lib = _host()
     if not _configured:
         lib.icpxh_last_error.restype = C.c_char_p
-        for name in ("icpxh_kdtree_new", "icpxh_ldt_new", "icpxh_icp_new", "icpxh_goicp_new"):
+        for name in ("icpxh_kdtree_new", "icpxh_ldt_new", "icpxh_icp_new", "icpxh_goicp_new", "icpxh_icp3d_new"):
             getattr(lib, name).restype = C.c_void_p
         lib.icpxh_kdtree_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
         lib.icpxh_ldt_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_uint32]
@@ -32,6 +32,10 @@ def _lib():
         lib.icpxh_ldt_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.icpxh_icp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
         lib.icpxh_icp_registration.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        lib.icpxh_icp3d_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+        lib.icpxh_icp3d_free.argtypes = [C.c_void_p]; lib.icpxh_icp3d_free.restype = None
+        lib.icpxh_icp3d_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_int,
+                                        C.c_double, C.c_void_p, C.c_void_p]
         lib.icpxh_goicp_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong]
         lib.icpxh_goicp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
         lib.icpxh_goicp_registration.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -177,6 +181,28 @@ class SingleThreadIcp:
     def __del__(self):
         if getattr(self, "_h", None):
             _lib().icpxh_icp_free(self._h); self._h = None
+
+
+class ICP3D:
+    """icp::ICP3D (the reference's src/jly_icp3d.cpp): Build(model) then Run(data, R, t) with optional trimming."""
+    def __init__(self, model, device=0):
+        self._m = np.ascontiguousarray(model, np.float64).reshape(-1, 3)
+        self._h = _new(_lib().icpxh_icp3d_new(device, _vp(self._m), self._m.shape[0]))
+        self.max_iter_def, self.err_diff_def, self.trim_fraction, self.do_trim = 10000, 0.000001, 0.0, True
+
+    def Run(self, data, R=None, t=None, max_iter=None, err_diff=None):
+        d = np.ascontiguousarray(data, np.float64).reshape(-1, 3)
+        R = np.ascontiguousarray(np.eye(3) if R is None else R, np.float64).reshape(9).copy()
+        t = np.ascontiguousarray(np.zeros(3) if t is None else t, np.float64).reshape(3).copy()
+        err = C.c_double(); it = C.c_size_t()
+        _ck(_lib().icpxh_icp3d_run(self._h, _vp(d), d.shape[0], _vp(R), _vp(t), self.max_iter_def if max_iter is None else max_iter,
+                                   self.err_diff_def if err_diff is None else err_diff, int(self.do_trim), self.trim_fraction,
+                                   C.byref(err), C.byref(it)))
+        return dict(R=R.reshape(3, 3), t=t, err=err.value, iterations=it.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().icpxh_icp3d_free(self._h); self._h = None
 
 
 class GoIcp:

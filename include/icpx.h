@@ -102,6 +102,14 @@ int icpx_icp_step(icpx_ctx* ctx, const double T[16], double sums[ICPX_NSUMS], in
  * host reads them. */
 int icpx_icp_step_async(icpx_ctx* ctx, const double T[16], double* sums_dev);
 
+/* Trimmed form of the same pass, the correspondence step of ICP3D::Run with do_trim
+ * (src/jly_icp3d.cpp:210-255): nearest target point of every transformed source point, then the sums of
+ * icpx_icp_step over the `keep` pairs with the smallest squared distances only (the reference sorts all
+ * pairs with qsort and uses the first num = (int)(n * (1 - trim_fraction))). Pairs with equal distance
+ * at the cut are taken in the order of the caller's source index; the reference's order there is
+ * whatever its qsort leaves. keep == n gives the sums of icpx_icp_step. */
+int icpx_icp_step_trimmed(icpx_ctx* ctx, const double T[16], uint64_t keep, double sums[ICPX_NSUMS]);
+
 /* ---- Euclidean distance transform --------------------------------------------------------------------- */
 
 /* Replaces LDT::LDT(cloud, div, cores) (src/testLDT.cpp:40-212) for the current target: voxelisation

@@ -400,6 +400,84 @@ int orc_icp(const float* src, int64_t nd, const float* tgt, int64_t nm, const do
     return icp_impl(src, nd, tgt, nm, guess, iters, nn_mode, per_iter_T, fin, mse_out, idx_last, threads, nullptr);
 }
 
+// ---- ICP3D (src/jly_icp3d.cpp:181-295) ---------------------------------------------------------------
+// The ICP of the original Go-ICP code that the reference carries: exact NN, optional trimming to the
+// num = (int)(n * (1 - trim_fraction)) pairs with the smallest squared distance, stop when the summed
+// error improves by less than err_diff * num. Restated as written, including: the two means are zeroed
+// once and keep accumulating over the iterations, and are always divided by n (:204-206, :244-252,
+// :262-263); R_ = V diag(1, 1, det(V U^T)) U^T with the determinant expanded along the first row
+// (:271-285). The reference sorts with qsort and a comparator that never reports equality (:157-160), so
+// its order among equal distances is unspecified; this restatement uses a stable sort (lower data index
+// first). model / data: doubles, row-major; R9 / t3 in-out; returns err_new, *iterations = passes made.
+double orc_icp3d_run(const double* model, int64_t m, const double* data, int64_t n, double* R9, double* t3, int64_t max_iter,
+                     double err_diff, int do_trim, double trim_fraction, int threads, int64_t* iterations) {
+    KdTree kd;
+    kd.n = m;
+    kd.work.resize(m);
+    for (int64_t i = 0; i < m; i++) {
+        for (int c = 0; c < 3; c++) kd.work[i].f[c] = model[3 * i + c];
+        kd.work[i].index = (int)i; kd.work[i].dim = 0;
+    }
+    kd.heap.resize(4 * m + 8); kd.used.assign(4 * m + 8, 0);
+    if (m > 0) kd.build(1, 0, m - 1, 0);
+    if (threads > 0) omp_set_num_threads(threads);
+    const int64_t num = do_trim ? (int64_t)(int)(n * (1 - trim_fraction)) : n;
+    struct Ref { double dis; int64_t id_data; int id_model; };
+    std::vector<Ref> pts(n);
+    std::vector<double> p_m(3 * num), p_d(3 * num);
+    double mu_m[3] = {0, 0, 0}, mu_d[3] = {0, 0, 0};
+    double R[3][3], t[3];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[i][j] = R9[3 * i + j]; t[i] = t3[i]; }
+    double err = -1, err_new = 0;
+    int64_t iter;
+    for (iter = 0; iter < max_iter; iter++) {
+        err_new = 0;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; i++) {
+            double q[3];
+            for (int r = 0; r < 3; r++) q[r] = R[r][0] * data[3 * i] + R[r][1] * data[3 * i + 1] + R[r][2] * data[3 * i + 2] + t[r];
+            KdTree::Best b{0.0, -1, false};
+            kd.search(q, 1, b);
+            pts[i] = Ref{b.d2, i, b.index};
+        }
+        if (do_trim) std::stable_sort(pts.begin(), pts.end(), [](const Ref& a, const Ref& b) { return a.dis < b.dis; });
+        for (int64_t i = 0; i < num; i++) {
+            for (int c = 0; c < 3; c++) { p_m[3 * i + c] = model[3 * (int64_t)pts[i].id_model + c]; mu_m[c] += p_m[3 * i + c]; }
+            const double* d = data + 3 * pts[i].id_data;
+            for (int r = 0; r < 3; r++) { p_d[3 * i + r] = R[r][0] * d[0] + R[r][1] * d[1] + R[r][2] * d[2] + t[r]; mu_d[r] += p_d[3 * i + r]; }
+            err_new += pts[i].dis;
+        }
+        if (err > 0 && err - err_new < err_diff * num) { iter++; break; }
+        err = err_new;
+        for (int c = 0; c < 3; c++) { mu_m[c] = mu_m[c] / (double)n; mu_d[c] = mu_d[c] / (double)n; }
+        double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // ~q_t * q_m: rows = data, columns = model
+        for (int64_t i = 0; i < num; i++)
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) H[r][c] += (p_d[3 * i + r] - mu_d[r]) * (p_m[3 * i + c] - mu_m[c]);
+        double U[3][3], W[3], V[3][3], R_[3][3];
+        svd3(H, U, W, V);
+        auto compose = [&](double d) {
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) R_[i][j] = V[i][0] * U[j][0] + V[i][1] * U[j][1] + d * V[i][2] * U[j][2];
+        };
+        compose(1.0);
+        const double a = R_[0][0] * (R_[1][1] * R_[2][2] - R_[1][2] * R_[2][1]);
+        const double b = -R_[0][1] * (R_[1][0] * R_[2][2] - R_[1][2] * R_[2][0]);
+        const double c = R_[0][2] * (R_[1][0] * R_[2][1] - R_[1][1] * R_[2][0]);
+        compose(a + b + c);
+        double t_[3], Rn[3][3], tn[3];
+        for (int r = 0; r < 3; r++) t_[r] = mu_m[r] - (R_[r][0] * mu_d[0] + R_[r][1] * mu_d[1] + R_[r][2] * mu_d[2]);
+        for (int r = 0; r < 3; r++) {
+            for (int cc = 0; cc < 3; cc++) Rn[r][cc] = R_[r][0] * R[0][cc] + R_[r][1] * R[1][cc] + R_[r][2] * R[2][cc];
+            tn[r] = (R_[r][0] * t[0] + R_[r][1] * t[1] + R_[r][2] * t[2]) + t_[r];
+        }
+        for (int r = 0; r < 3; r++) { for (int cc = 0; cc < 3; cc++) R[r][cc] = Rn[r][cc]; t[r] = tn[r]; }
+    }
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R9[3 * i + j] = R[i][j]; t3[i] = t[i]; }
+    if (iterations) *iterations = iter;
+    return err_new;
+}
+
 // ---- LDT ------------------------------------------------------------------------------------------
 
 void orc_ldt_box(const float* pts, int64_t n, uint32_t div, float* min3, float* cellLen) {

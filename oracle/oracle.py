@@ -40,6 +40,7 @@ def ref():
         _ref = C.CDLL(path)
         _ref.ref_dt3d_build.restype = C.c_void_p
         _ref.ref_icp3d_run.restype = C.c_double
+        _ref.ref_icp3d_run_ex.restype = C.c_double
     return _ref
 
 
@@ -110,6 +111,18 @@ def icp(src, tgt, iters, guess=None, nn_mode=1, threads=0):
                        C.c_int(nn_mode), _vp(per), _vp(fin), _vp(mse), _vp(idx), C.c_int(threads))
     assert rc == 0
     return dict(per_iter_T=per.reshape(iters, 4, 4), T=fin.reshape(4, 4), mse=mse, idx_last=idx)
+
+
+def icp3d_run(model, data, max_iter=10000, err_diff=0.000001, do_trim=True, trim_fraction=0.0, R=None, t=None, threads=0):
+    """ICP3D::Run restated (src/jly_icp3d.cpp:181-295). Returns dict(R, t, err, iterations)."""
+    model, data = f64(model), f64(data)
+    R = f64(np.eye(3) if R is None else R).copy().reshape(9); t = f64(np.zeros(3) if t is None else t).copy()
+    it = C.c_int64()
+    f = lib().orc_icp3d_run
+    f.restype = C.c_double
+    err = f(_vp(model), C.c_int64(model.shape[0]), _vp(data), C.c_int64(data.shape[0]), _vp(R), _vp(t), C.c_int64(max_iter),
+            C.c_double(err_diff), C.c_int(int(do_trim)), C.c_double(trim_fraction), C.c_int(threads), C.byref(it))
+    return dict(R=R.reshape(3, 3), t=t, err=err, iterations=it.value)
 
 
 # ---- LDT ------------------------------------------------------------------------------------------
@@ -217,6 +230,14 @@ def ref_icp3d_run(model, data, iters, R=None, t=None):
     model, data = f64(model), f64(data)
     R = f64(np.eye(3) if R is None else R).copy().reshape(9); t = f64(np.zeros(3) if t is None else t).copy()
     err = ref().ref_icp3d_run(_vp(model), C.c_int64(model.shape[0]), _vp(data), C.c_int64(data.shape[0]), _vp(R), _vp(t), C.c_int64(iters))
+    return R.reshape(3, 3), t, err
+
+
+def ref_icp3d_run_ex(model, data, max_iter, err_diff, do_trim, trim_fraction, R=None, t=None):
+    model, data = f64(model), f64(data)
+    R = f64(np.eye(3) if R is None else R).copy().reshape(9); t = f64(np.zeros(3) if t is None else t).copy()
+    err = ref().ref_icp3d_run_ex(_vp(model), C.c_int64(model.shape[0]), _vp(data), C.c_int64(data.shape[0]), _vp(R), _vp(t),
+                                 C.c_int64(max_iter), C.c_double(err_diff), C.c_int(int(do_trim)), C.c_double(trim_fraction))
     return R.reshape(3, 3), t, err
 
 

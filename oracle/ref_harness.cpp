@@ -50,6 +50,20 @@ double ref_icp3d_run(const double* model, int64_t m, const double* data, int64_t
     return err;
 }
 
+// ICP3D<double>::Run with the caller's trimming and stop settings (public fields do_trim, trim_fraction; arguments
+// max_iter, err_diff).
+double ref_icp3d_run_ex(const double* model, int64_t m, const double* data, int64_t n, double* R9, double* t3, int64_t max_iter,
+                        double err_diff, int do_trim, double trim_fraction) {
+    ICP3D<double> icp;
+    icp.do_trim = do_trim != 0;
+    icp.trim_fraction = trim_fraction;
+    icp.Build(const_cast<double*>(model), (size_t)m);
+    Matrix R(3, 3, R9), t(3, 1, t3);
+    double err = icp.Run(const_cast<double*>(data), (size_t)n, R, t, (size_t)max_iter, err_diff);
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R9[3 * i + j] = R.val[i][j]; t3[i] = t.val[i][0]; }
+    return err;
+}
+
 // DT3D (src/jly_3ddt.cpp:731-856). expandFactor is left uninitialised by the constructor (:727-729);
 // the harness sets it. Returns an opaque handle.
 void* ref_dt3d_build(const double* x, const double* y, const double* z, int n, double expandFactor) {

@@ -69,6 +69,29 @@ def test_icp_with_guess(oracle, bunny000, bunny045):
     assert np.abs(got["T"] - ref["T"]).max() < 1e-10
 
 
+@pytest.mark.parametrize("do_trim,frac,err_diff,max_iter", [(False, 0.0, -1.0, 10), (True, 0.1, -1.0, 10), (True, 0.25, 0.000001, 200)])
+def test_icp3d_class(oracle, bunny000, bunny045, do_trim, frac, err_diff, max_iter):
+    """icp::ICP3D (src/jly_icp3d.cpp:181-295) on the GPU against the oracle's restatement, which the CPU suite pins on
+    the reference's own ICP3D<double>: R, t within 1e-5 (north-star tolerance; observed <= 1e-8, from queries with two
+    equidistant target points, where the GPU takes the lowest index and the kd-tree the first visited), same number of passes."""
+    from icp_amd.host import ICP3D
+    model = bunny045.astype(np.float64); data = bunny000[::2].astype(np.float64)
+    icp = ICP3D(model)
+    icp.do_trim, icp.trim_fraction = do_trim, frac
+    got = icp.Run(data, max_iter=max_iter, err_diff=err_diff)
+    want = oracle.icp3d_run(model, data, max_iter, err_diff, do_trim, frac)
+    np.testing.assert_allclose(got["R"], want["R"], atol=1e-5)
+    np.testing.assert_allclose(got["t"], want["t"], atol=1e-5)
+    assert np.abs(got["R"] - want["R"]).max() < 1e-7 and np.abs(got["t"] - want["t"]).max() < 1e-7
+    assert got["iterations"] == want["iterations"]
+    assert abs(got["err"] - want["err"]) <= 1e-5 * want["err"]
+    # a second Run from a guess reuses the built model
+    g = rigid([0, 0, 1], 3.0, [0.001, 0, 0])
+    got2 = icp.Run(data, R=g[:3, :3], t=g[:3, 3], max_iter=3, err_diff=-1.0)
+    want2 = oracle.icp3d_run(model, data, 3, -1.0, do_trim, frac, R=g[:3, :3], t=g[:3, 3])
+    np.testing.assert_allclose(got2["R"], want2["R"], atol=1e-7)
+
+
 def test_goicp_as_committed(oracle, bunny000, bun270):
     """The committed GoIcp::registration stops after the initial ICP (src/GoIcp.cpp:189)."""
     from icp_amd.host import GoIcp, LDT

@@ -44,3 +44,25 @@ def test_icp_step_async_on_torch_stream(gpu_ctx, oracle, bunny000, bunny045):
             assert np.array_equal(doubled, 2 * ref)
     finally:
         gpu_ctx.reset_stream()
+
+
+def test_icp_step_trimmed(gpu_ctx, oracle, bunny000, bunny045):
+    """Sums over the `keep` closest pairs (ICP3D's trimming, src/jly_icp3d.cpp:236-255); keep == n equals the plain step."""
+    gpu_ctx.set_target(bunny045)
+    gpu_ctx.set_source(bunny000)
+    T = rigid([0.2, -1, 0.4], 8.0, [0.003, 0.001, -0.002])
+    n = bunny000.shape[0]
+    p = bunny000.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    idx, d2 = oracle.nn_brute(np.ascontiguousarray(p), bunny045)
+    order = np.argsort(d2, kind="stable")
+    for keep in (n, int(n * 0.9), 1000, 1, 0):
+        sel = order[:keep]
+        q = bunny045[idx[sel]].astype(np.float64)
+        ref = np.empty(16)
+        ref[0:3] = p[sel].sum(0); ref[3:6] = q.sum(0); ref[6:15] = (p[sel].T @ q).reshape(9); ref[15] = d2[sel].sum()
+        got = gpu_ctx.icp_step_trimmed(T, keep)
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(gpu_ctx.icp_step_trimmed(T, n), gpu_ctx.icp_step(T), rtol=1e-13, atol=1e-13)
+    from icp_amd import IcpxError
+    with pytest.raises(IcpxError):
+        gpu_ctx.icp_step_trimmed(T, n + 1)

@@ -71,3 +71,20 @@ def test_icp_agrees_with_icp3d(ref, bunny000, bunny045):
     R, t, err = ref.ref_icp3d_run(bunny045.astype(np.float64), bunny000.astype(np.float64), 30)
     mine = ref.icp(bunny000, bunny045, 30, nn_mode=0)["T"]
     assert np.abs(mine[:3, :3] - R).max() < 2e-3 and np.abs(mine[:3, 3] - t).max() < 2e-3
+
+
+@pytest.mark.parametrize("do_trim,frac,err_diff,max_iter", [(False, 0.0, -1.0, 6), (True, 0.1, -1.0, 6), (True, 0.25, 0.000001, 200)])
+def test_icp3d_restatement_equals_icp3d_run(ref, bunny000, bunny045, do_trim, frac, err_diff, max_iter):
+    """oracle.icp3d_run against ICP3D<double>::Run compiled from src/jly_icp3d.cpp: trimming, the accumulating
+    means and the stop test. The only licence taken is the order of equal distances at the trim cut (the
+    reference's qsort comparator never reports equality; the scans hold many equal distances): observed 1e-11
+    after 6 passes and 7e-8 after 20, asserted at 1e-6, and the stop test fires in the same pass."""
+    from oracle import oracle as O
+    model = bunny045[::2].astype(np.float64); data = bunny000[::4].astype(np.float64)
+    got = O.icp3d_run(model, data, max_iter, err_diff, do_trim, frac)
+    R, t, err = O.ref_icp3d_run_ex(model, data, max_iter, err_diff, do_trim, frac)
+    np.testing.assert_allclose(got["R"], R, atol=1e-6)
+    np.testing.assert_allclose(got["t"], t, atol=1e-6)
+    assert abs(got["err"] - err) <= 1e-6 * err
+    if err_diff > 0:
+        assert 2 <= got["iterations"] < max_iter      # the stop test fired
