@@ -76,6 +76,40 @@ def test_edt_pool_and_spill_tiers(oracle, bunny045, tune, monkeypatch):
         ctx.close()
 
 
+def test_edt_maximum_resolution(gpu_ctx, oracle, bunny045):
+    """div = ICPX_MAX_DIV (1023): 1.07e9 voxels, 16 z-words per row, ten-bit sites. Too large for the oracle's full
+    three-pass run in a test, so: box and splat against the oracle, brute-force squared distances at sampled
+    voxels, and two properties that hold for an exact EDT at any size (zero exactly on the occupied voxels;
+    sqrt(d) changes by at most 1 between face neighbours)."""
+    import torch
+    div = 1023
+    gpu_ctx.set_target(bunny045)
+    gpu_ctx.edt_build(div)
+    info = gpu_ctx.edt_info()
+    mn, cell = oracle.ldt_box(bunny045, div)
+    assert np.array_equal(info["min"], mn) and info["cell"] == cell
+    occ, dropped = oracle.ldt_splat(bunny045, div, mn, cell)
+    assert info["occupied"] == int(occ.sum()) and info["dropped"] == dropped
+    sq = torch.empty((div, div, div), dtype=torch.int32, device="cuda")
+    gpu_ctx.edt_read(sq)
+    assert int((sq == 0).sum().item()) == info["occupied"]
+    occ_idx = np.argwhere(occ)
+    assert bool((sq[torch.from_numpy(occ_idx).cuda().unbind(1)] == 0).all().item())
+    rng = np.random.default_rng(5)
+    near = occ_idx[rng.integers(0, len(occ_idx), 1500)] + rng.integers(-12, 13, (1500, 3))
+    vox = np.concatenate([rng.integers(0, div, (1500, 3)), np.clip(near, 0, div - 1)]).astype(np.int32)
+    want = oracle.edt_brute_samples(occ, vox)
+    got = sq[torch.from_numpy(vox.astype(np.int64)).cuda().unbind(1)].cpu().numpy()
+    assert np.array_equal(got, want)
+    for axis in range(3):   # |sqrt(a) - sqrt(b)| <= 1  <=>  a <= b + 2 sqrt(b) + 1 (both ways), in float64 per 64-plane slab
+        for x0 in range(0, div, 64):
+            slab = sq[x0:min(x0 + 65, div)].to(torch.float64) if axis == 0 else sq[x0:min(x0 + 64, div)].to(torch.float64)
+            a = slab.narrow(axis, 0, slab.shape[axis] - 1); b = slab.narrow(axis, 1, slab.shape[axis] - 1)
+            if a.numel() == 0:
+                continue
+            assert bool((a <= b + 2 * b.sqrt() + 1 + 1e-6).all().item()) and bool((b <= a + 2 * a.sqrt() + 1 + 1e-6).all().item())
+
+
 def test_edt_single_voxel_and_brute(gpu_ctx, oracle):
     pts = np.array([[0.31, 0.52, 0.77]], np.float32)
     mn = np.zeros(3, np.float32); cell = np.float32(1.0 / 40)
