@@ -131,6 +131,17 @@ class Context:
             mn = np.ascontiguousarray(box[0], np.float32)
             self._ck(self._lib.icpx_edt_build_box(self._h, div, mn.ctypes.data_as(C.c_void_p), C.c_float(box[1])))
 
+    def edt_build_round(self, div, min3, scale):
+        """Grid with DT3D's voxel rule: int((p - min3) * scale + 0.5)."""
+        mn = np.ascontiguousarray(min3, np.float64)
+        self._ck(self._lib.icpx_edt_build_round(self._h, div, mn.ctypes.data_as(C.c_void_p), C.c_double(scale)))
+
+    def edt_lookup_round(self, q):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        out = np.empty(q.shape[0], np.float32)
+        self._ck(self._lib.icpx_edt_lookup_round(self._h, q.ctypes.data_as(C.c_void_p), q.shape[0], HOST, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def edt_rebuild_async(self):
         self._ck(self._lib.icpx_edt_rebuild_async(self._h))
 

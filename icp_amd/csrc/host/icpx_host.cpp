@@ -210,6 +210,55 @@ const std::vector<float>& LDT::grid() {
     return g_;
 }
 
+// ---- DT3D --------------------------------------------------------------------------------------------------
+
+DT3D::DT3D(DevicePtr d) : SIZE(300), scale(0), expandFactor(2.0), xMin(0), xMax(0), yMin(0), yMax(0), zMin(0), zMax(0),
+                          dev(d ? d : std::make_shared<Device>(0)) {}   // the reference leaves expandFactor unset; upstream Go-ICP uses 2
+
+void DT3D::Build(const double* x, const double* y, const double* z, int num) {
+    if (!x || !y || !z || num < 1) throw IcpxFailure(ICPX_EINVAL, "DT3D::Build: empty cloud");
+    xMin = xMax = x[0]; yMin = yMax = y[0]; zMin = zMax = z[0];
+    for (int i = 1; i < num; i++) {
+        if (xMin > x[i]) xMin = x[i];
+        if (xMax < x[i]) xMax = x[i];
+        if (yMin > y[i]) yMin = y[i];
+        if (yMax < y[i]) yMax = y[i];
+        if (zMin > z[i]) zMin = z[i];
+        if (zMax < z[i]) zMax = z[i];
+    }
+    // :743-764, statement by statement (the second assignment of each pair sees the first)
+    const double xCenter = (xMin + xMax) / 2, yCenter = (yMin + yMax) / 2, zCenter = (zMin + zMax) / 2;
+    xMin = xCenter - expandFactor * (xMax - xCenter);
+    xMax = xCenter + expandFactor * (xMax - xCenter);
+    yMin = yCenter - expandFactor * (yMax - yCenter);
+    yMax = yCenter + expandFactor * (yMax - yCenter);
+    zMin = zCenter - expandFactor * (zMax - zCenter);
+    zMax = zCenter + expandFactor * (zMax - zCenter);
+    double max = xMax - xMin > yMax - yMin ? xMax - xMin : yMax - yMin;
+    max = max > zMax - zMin ? max : zMax - zMin;
+    xMin = xCenter - max / 2; xMax = xCenter + max / 2;
+    yMin = yCenter - max / 2; yMax = yCenter + max / 2;
+    zMin = zCenter - max / 2; zMax = zCenter + max / 2;
+    SIZE = 300;
+    scale = SIZE / max;
+    cloud_ = std::make_shared<PointCloudT>();
+    cloud_->points.resize((size_t)num);
+    for (int i = 0; i < num; i++) cloud_->points[i] = Point3f((float)x[i], (float)y[i], (float)z[i]);
+    ensure_target_on(dev, cloud_);
+    const double mn[3] = {xMin, yMin, zMin};
+    dev->check(icpx_edt_build_round(dev->ctx(), (uint32_t)SIZE, mn, scale));
+    dev->edt_div = 0;   // the context's grid no longer follows LDT's box rule
+}
+
+void DT3D::Distance(const double* xyz, size_t n, float* out) { dev->check(icpx_edt_lookup_round(dev->ctx(), xyz, n, ICPX_HOST, out)); }
+
+float DT3D::Distance(double x, double y, double z) {
+    const double q[3] = {x, y, z};
+    float out = 0;
+    Distance(q, 1, &out);
+    return out;
+}
+
 // ---- ICP3D -------------------------------------------------------------------------------------------------
 
 ICP3D::ICP3D(DevicePtr d) : err_diff_def(0.000001), max_iter_def(10000), trim_fraction(0), do_trim(true), dev(d ? d : std::make_shared<Device>(0)) {}
@@ -822,6 +871,29 @@ int icpxh_icp_registration(void* p, const double* guess16, double* T_out16, doub
         if (resN3) std::memcpy(resN3, r.resN3.data.data(), r.resN3.data.size() * sizeof(double));
         if (idx_last) std::memcpy(idx_last, h->icp->Neighbour.pointsPARA.data(), sizeof(int32_t) * h->icp->Nd);
     });
+}
+
+// ---- DT3D
+struct HDt3d { DevicePtr dev; std::unique_ptr<DT3D> dt; };
+// xyz: n x 3 doubles, row-major. info8 receives SIZE, scale, xMin, yMin, zMin, xMax, yMax, zMax.
+void* icpxh_dt3d_new(int device, const double* xyz, size_t n, double expandFactor, double* info8) {
+    HDt3d* h = new HDt3d;
+    if (guard([&] {
+            h->dev = std::make_shared<Device>(device);
+            h->dt.reset(new DT3D(h->dev));
+            h->dt->expandFactor = expandFactor;
+            std::vector<double> x(n), y(n), z(n);
+            for (size_t i = 0; i < n; i++) { x[i] = xyz[3 * i]; y[i] = xyz[3 * i + 1]; z[i] = xyz[3 * i + 2]; }
+            h->dt->Build(x.data(), y.data(), z.data(), (int)n);
+            const DT3D& d = *h->dt;
+            const double v[8] = {(double)d.SIZE, d.scale, d.xMin, d.yMin, d.zMin, d.xMax, d.yMax, d.zMax};
+            std::memcpy(info8, v, sizeof v);
+        })) { delete h; return nullptr; }
+    return h;
+}
+void icpxh_dt3d_free(void* p) { delete (HDt3d*)p; }
+int icpxh_dt3d_distance(void* p, const double* q, size_t n, float* out) {
+    return guard([&] { HDt3d* h = (HDt3d*)p; if (n == 1) out[0] = h->dt->Distance(q[0], q[1], q[2]); else h->dt->Distance(q, n, out); });
 }
 
 // ---- ICP3D

@@ -141,6 +141,24 @@ private:
     std::vector<float> g_;
 };
 
+// The distance-transform class of the original Go-ICP code that the reference carries (src/jly_3ddt.h:37-52,
+// src/jly_3ddt.cpp:727-856): cubic grid of SIZE = 300 cells around the cloud's bounding box enlarged by
+// expandFactor, rounded voxel indices. The grid holds exact distances (the reference's DEuclidean pass is
+// an approximation of them).
+class DT3D {
+public:
+    explicit DT3D(DevicePtr dev = nullptr);
+    void Build(const double* x, const double* y, const double* z, int num);   // :731-819
+    float Distance(double x, double y, double z);                              // :821-856
+    void Distance(const double* xyz, size_t n, float* out);                    // batch form, n x 3 row-major
+    int SIZE;
+    double scale, expandFactor;
+    double xMin, xMax, yMin, yMax, zMin, zMax;
+    DevicePtr dev;
+private:
+    PointCloudTPtr cloud_;
+};
+
 struct Correspondance {     // src/SingleThreadIcp.cpp:37-44
     std::vector<int> pointsPARA;
     Matrix3d covariance;

@@ -61,6 +61,8 @@ struct icpx_ctx {
     int edt_words = 0;       // 64-bit words per (x,y) bit row
     float edt_min[3] = {0, 0, 0};
     float edt_cell = 0.f;
+    bool edt_round = false;  // grid built with DT3D's convention: voxel = int((p - dmin) * scale + 0.5) in double
+    double edt_dmin[3] = {0, 0, 0}, edt_scale = 0.0;
     // Envelope passes: site groups (= waves) per 64 rows, private LDS levels per lane and group, pool
     // chunks per workgroup. 4 x 28 x 64 x 6 bytes + 40 chunks x 48 bytes + header = 47 KiB: three
     // workgroups (12 waves) per CU; measured best on the 300^3 bunny grid among the shapes tried.

@@ -46,6 +46,22 @@ __global__ void k_edt_splat(const float* __restrict__ pts, size_t n, float mnx, 
     atomicOr(&bits[((size_t)ix * div + iy) * W + (iz >> 6)], 1ull << (iz & 63));
 }
 
+// DT3D's voxel rule (src/jly_3ddt.cpp:30, :792-798): int((p - min) * scale + 0.5) per axis in double, points
+// outside the grid skipped.
+__global__ void k_edt_splat_round(const float* __restrict__ pts, size_t n, double mnx, double mny, double mnz, double scale, int div,
+                                  int W, u64* __restrict__ bits, u64* __restrict__ counters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ix = (int)(((double)pts[3 * i] - mnx) * scale + 0.5);
+    const int iy = (int)(((double)pts[3 * i + 1] - mny) * scale + 0.5);
+    const int iz = (int)(((double)pts[3 * i + 2] - mnz) * scale + 0.5);
+    if (ix < 0 || iy < 0 || iz < 0 || ix >= div || iy >= div || iz >= div) {
+        atomicAdd(&counters[1], 1ull);
+        return;
+    }
+    atomicOr(&bits[((size_t)ix * div + iy) * W + (iz >> 6)], 1ull << (iz & 63));
+}
+
 // ---- census ------------------------------------------------------------------------------------------------
 // For every non-empty row (x, y) and every 64-wide z chunk c the census writes one 16-byte record that
 // pass zy consumes: the chunk's own occupancy word, the nearest set bit below / above the chunk, and y.
@@ -556,6 +572,26 @@ __global__ void k_edt_lookup(const int* __restrict__ sq, int div, float mnx, flo
     out[i] = edt_distance(sq, div, mnx, mny, mnz, cell, q[3 * i], q[3 * i + 1], q[3 * i + 2]);
 }
 
+// DT3D::Distance (src/jly_3ddt.cpp:821-856) on the exact grid: rounded voxel index; inside the grid the
+// stored distance sqrt(sq) / scale as float; outside, the clamped voxel's distance plus the overshoot in
+// cells (float a, b, c; their squares summed in float; sqrt and division in double) over scale.
+__global__ void k_edt_lookup_round(const int* __restrict__ sq, int div, double mnx, double mny, double mnz, double scale,
+                                   const double* __restrict__ q, size_t n, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x = (int)((q[3 * i] - mnx) * scale + 0.5);
+    int y = (int)((q[3 * i + 1] - mny) * scale + 0.5);
+    int z = (int)((q[3 * i + 2] - mnz) * scale + 0.5);
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (x < 0) { a = (float)x; x = 0; } else if (x >= div) { a = (float)(x - div + 1); x = div - 1; }
+    if (y < 0) { b = (float)y; y = 0; } else if (y >= div) { b = (float)(y - div + 1); y = div - 1; }
+    if (z < 0) { c = (float)z; z = 0; } else if (z >= div) { c = (float)(z - div + 1); z = div - 1; }
+    const float g = (float)(__dsqrt_rn((double)sq[((size_t)x * div + y) * div + z]) / scale);
+    if (a == 0.f && b == 0.f && c == 0.f) { out[i] = g; return; }
+    const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fmul_rn(c, c));
+    out[i] = (float)(__dsqrt_rn((double)s2) / scale + (double)g);
+}
+
 }  // namespace
 
 // Two sets of uint64 x 8 behind the occupancy bits, used by alternate builds: {occupied voxels, dropped
@@ -616,8 +652,12 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
     // build's counter set (edt_prepare clears everything when the buffers are (re)allocated or resized).
     ctx->edt_epoch ^= 1;
     u64* counters = edt_counters(ctx);
-    edt_launch(k_edt_splat, dim3((unsigned)((ctx->nt + 255) / 256)), dim3(256), 0, s, ev, 0, ctx->tgt_xyz.as<float>(), ctx->nt,
-               ctx->edt_min[0], ctx->edt_min[1], ctx->edt_min[2], ctx->edt_cell, div, W, ctx->edt_bits.as<u64>(), counters);
+    if (ctx->edt_round)
+        edt_launch(k_edt_splat_round, dim3((unsigned)((ctx->nt + 255) / 256)), dim3(256), 0, s, ev, 0, (const float*)ctx->tgt_xyz.as<float>(),
+                   ctx->nt, ctx->edt_dmin[0], ctx->edt_dmin[1], ctx->edt_dmin[2], ctx->edt_scale, div, W, ctx->edt_bits.as<u64>(), counters);
+    else
+        edt_launch(k_edt_splat, dim3((unsigned)((ctx->nt + 255) / 256)), dim3(256), 0, s, ev, 0, (const float*)ctx->tgt_xyz.as<float>(), ctx->nt,
+                   ctx->edt_min[0], ctx->edt_min[1], ctx->edt_min[2], ctx->edt_cell, div, W, ctx->edt_bits.as<u64>(), counters);
     edt_launch(k_edt_census, dim3(div), dim3(64 * nchunk), 0, s, ev, 1, ctx->edt_bits.as<u64>(), div, W, ctx->edt_rowlist.as<RowRec>(),
                ctx->edt_rowcnt.as<int>(), counters, edt_counter_set(ctx, ctx->edt_epoch ^ 1), (div + 15) / 16 * 16 + 16,
                ctx->edt_planelist.as<int>());
@@ -688,12 +728,8 @@ static int edt_prepare(icpx_ctx* ctx, uint32_t div) {
     return ICPX_OK;
 }
 
-extern "C" int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[3], float cell_len) {
-    if (!ctx) return ICPX_EINVAL;
-    if (!min3 || !(cell_len > 0.f)) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_build_box: bad box");
-    ICPX_TRY(edt_prepare(ctx, div));
-    ctx->edt_min[0] = min3[0]; ctx->edt_min[1] = min3[1]; ctx->edt_min[2] = min3[2];
-    ctx->edt_cell = cell_len;
+// Runs the kernels until a build fits its stack storage (at most twice) and checks that the grid is not empty.
+static int edt_build_attempts(icpx_ctx* ctx) {
     for (int attempt = 0; attempt < 2; attempt++) {
         ICPX_TRY(icpx_edt_run(ctx));
         u64 counters[8];
@@ -708,6 +744,49 @@ extern "C" int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[
         ICPX_TRY(icpx_reserve(ctx, ctx->edt_spill, edt_spill_bytes(ctx)));
     }
     ctx->edt_ready = true;
+    return ICPX_OK;
+}
+
+extern "C" int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[3], float cell_len) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!min3 || !(cell_len > 0.f)) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_build_box: bad box");
+    ICPX_TRY(edt_prepare(ctx, div));
+    ctx->edt_round = false;
+    ctx->edt_min[0] = min3[0]; ctx->edt_min[1] = min3[1]; ctx->edt_min[2] = min3[2];
+    ctx->edt_cell = cell_len;
+    return edt_build_attempts(ctx);
+}
+
+extern "C" int icpx_edt_build_round(icpx_ctx* ctx, uint32_t div, const double min3[3], double scale) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!min3 || !(scale > 0.0)) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_build_round: bad box");
+    ICPX_TRY(edt_prepare(ctx, div));
+    ctx->edt_round = true;
+    for (int k = 0; k < 3; k++) { ctx->edt_dmin[k] = min3[k]; ctx->edt_min[k] = (float)min3[k]; }
+    ctx->edt_scale = scale;
+    ctx->edt_cell = (float)(1.0 / scale);
+    return edt_build_attempts(ctx);
+}
+
+extern "C" int icpx_edt_lookup_round(icpx_ctx* ctx, const double* xyz, size_t n, int where, float* dist) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->edt_ready || !ctx->edt_round) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_lookup_round: no grid built with icpx_edt_build_round");
+    if (n == 0) return ICPX_OK;
+    if (!xyz || !dist) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_lookup_round: NULL buffer");
+    ICPX_TRY(icpx_bind(ctx));
+    const double* dq = xyz; float* dout = dist;
+    if (where == ICPX_HOST) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->scratch_q, n * 3 * sizeof(double)));
+        ICPX_TRY(icpx_reserve(ctx, ctx->scratch_d2, n * sizeof(float)));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        dq = ctx->scratch_q.as<double>(); dout = ctx->scratch_d2.as<float>();
+    }
+    hipLaunchKernelGGL(k_edt_lookup_round, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->edt_sq.as<int>(), (int)ctx->div,
+                       ctx->edt_dmin[0], ctx->edt_dmin[1], ctx->edt_dmin[2], ctx->edt_scale, dq, n, dout);
+    ICPX_TRY(icpx_launch_check(ctx, "k_edt_lookup_round"));
+    if (where == ICPX_HOST)
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(dist, dout, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICPX_OK;
 }
 
@@ -780,6 +859,7 @@ extern "C" int icpx_edt_grid_ptr(icpx_ctx* ctx, const int32_t** sq_dev) {
 extern "C" int icpx_edt_lookup(icpx_ctx* ctx, const float* xyz, size_t n, int where, float* dist) {
     if (!ctx) return ICPX_EINVAL;
     if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_lookup: no EDT has been built");
+    if (ctx->edt_round) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_lookup: the grid was built with icpx_edt_build_round (use icpx_edt_lookup_round)");
     if (n == 0) return ICPX_OK;
     if (!xyz || !dist) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_lookup: NULL buffer");
     ICPX_TRY(icpx_bind(ctx));

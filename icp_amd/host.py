@@ -17,7 +17,7 @@ def _lib():
     lib = _host()
     if not _configured:
         lib.icpxh_last_error.restype = C.c_char_p
-        for name in ("icpxh_kdtree_new", "icpxh_ldt_new", "icpxh_icp_new", "icpxh_goicp_new", "icpxh_icp3d_new"):
+        for name in ("icpxh_kdtree_new", "icpxh_ldt_new", "icpxh_icp_new", "icpxh_goicp_new", "icpxh_icp3d_new", "icpxh_dt3d_new"):
             getattr(lib, name).restype = C.c_void_p
         lib.icpxh_kdtree_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
         lib.icpxh_ldt_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_uint32]
@@ -32,6 +32,9 @@ def _lib():
         lib.icpxh_ldt_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.icpxh_icp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
         lib.icpxh_icp_registration.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        lib.icpxh_dt3d_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]
+        lib.icpxh_dt3d_free.argtypes = [C.c_void_p]; lib.icpxh_dt3d_free.restype = None
+        lib.icpxh_dt3d_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.icpxh_icp3d_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
         lib.icpxh_icp3d_free.argtypes = [C.c_void_p]; lib.icpxh_icp3d_free.restype = None
         lib.icpxh_icp3d_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_int,
@@ -181,6 +184,26 @@ class SingleThreadIcp:
     def __del__(self):
         if getattr(self, "_h", None):
             _lib().icpxh_icp_free(self._h); self._h = None
+
+
+class DT3D:
+    """icp::DT3D (the reference's src/jly_3ddt.cpp:727-856): Build on a cloud, Distance(queries)."""
+    def __init__(self, pts, expandFactor=2.0, device=0):
+        p = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        info = np.empty(8)
+        self._h = _new(_lib().icpxh_dt3d_new(device, _vp(p), p.shape[0], expandFactor, _vp(info)))
+        self.SIZE, self.scale = int(info[0]), info[1]
+        self.xMin, self.yMin, self.zMin, self.xMax, self.yMax, self.zMax = info[2:]
+
+    def Distance(self, q):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        out = np.empty(q.shape[0], np.float32)
+        _ck(_lib().icpxh_dt3d_distance(self._h, _vp(q), q.shape[0], _vp(out)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().icpxh_dt3d_free(self._h); self._h = None
 
 
 class ICP3D:

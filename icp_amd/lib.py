@@ -44,6 +44,8 @@ ICPX_SYMBOLS = {
     "icpx_icp_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "icpx_edt_build": (C.c_int, [C.c_void_p, C.c_uint32]),
     "icpx_edt_build_box": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_float]),
+    "icpx_edt_build_round": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_double]),
+    "icpx_edt_lookup_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "icpx_edt_rebuild_async": (C.c_int, [C.c_void_p]),
     "icpx_edt_rebuild_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "icpx_edt_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -121,6 +121,16 @@ int icpx_edt_build(icpx_ctx* ctx, uint32_t div);
  * voxel falls outside the grid are dropped. */
 int icpx_edt_build_box(icpx_ctx* ctx, uint32_t div, const float min3[3], float cell_len);
 
+/* The same exact transform on a grid with DT3D's convention (src/jly_3ddt.cpp:792-798, :821-856): voxel index
+ * int((p - min) * scale + 0.5) per axis in double. DT3D::Build derives min and scale from the cloud
+ * (:731-764); the caller passes them (icp::DT3D in the host library applies that rule). The grid then
+ * serves icpx_edt_lookup_round, which reproduces DT3D::Distance: rounded index; inside the grid
+ * (float)(sqrt(squared cells) / scale); outside, the clamped voxel's value plus the overshoot in cells over
+ * scale. DT3D itself fills its grid with an approximate propagation (DEuclidean); the values here are the
+ * exact distances, so they differ from DT3D's by its approximation error. n x 3 doubles in, n floats out. */
+int icpx_edt_build_round(icpx_ctx* ctx, uint32_t div, const double min3[3], double scale);
+int icpx_edt_lookup_round(icpx_ctx* ctx, const double* q_xyz, size_t n, int where, float* dist);
+
 /* Only the kernels of icpx_edt_build, enqueued on the stream (box and buffers from the previous
  * icpx_edt_build* call are reused): the timed region of the EDT benchmark. */
 int icpx_edt_rebuild_async(icpx_ctx* ctx);

@@ -400,6 +400,64 @@ int orc_icp(const float* src, int64_t nd, const float* tgt, int64_t nm, const do
     return icp_impl(src, nd, tgt, nm, guess, iters, nn_mode, per_iter_T, fin, mse_out, idx_last, threads, nullptr);
 }
 
+// ---- DT3D convention (src/jly_3ddt.cpp:731-856) -----------------------------------------------------------
+// Box rule of DT3D::Build (:732-764): info8 = SIZE, scale, xMin, yMin, zMin, xMax, yMax, zMax.
+void orc_dt3d_box(const double* xyz, int64_t n, double expandFactor, double* info8) {
+    double xMin = xyz[0], xMax = xyz[0], yMin = xyz[1], yMax = xyz[1], zMin = xyz[2], zMax = xyz[2];
+    for (int64_t i = 1; i < n; i++) {
+        const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (xMin > x) xMin = x;
+        if (xMax < x) xMax = x;
+        if (yMin > y) yMin = y;
+        if (yMax < y) yMax = y;
+        if (zMin > z) zMin = z;
+        if (zMax < z) zMax = z;
+    }
+    const double xCenter = (xMin + xMax) / 2, yCenter = (yMin + yMax) / 2, zCenter = (zMin + zMax) / 2;
+    xMin = xCenter - expandFactor * (xMax - xCenter);
+    xMax = xCenter + expandFactor * (xMax - xCenter);
+    yMin = yCenter - expandFactor * (yMax - yCenter);
+    yMax = yCenter + expandFactor * (yMax - yCenter);
+    zMin = zCenter - expandFactor * (zMax - zCenter);
+    zMax = zCenter + expandFactor * (zMax - zCenter);
+    double max = xMax - xMin > yMax - yMin ? xMax - xMin : yMax - yMin;
+    max = max > zMax - zMin ? max : zMax - zMin;
+    info8[0] = 300; info8[1] = 300 / max;
+    info8[2] = xCenter - max / 2; info8[3] = yCenter - max / 2; info8[4] = zCenter - max / 2;
+    info8[5] = xCenter + max / 2; info8[6] = yCenter + max / 2; info8[7] = zCenter + max / 2;
+}
+
+// Occupancy with ROUND(x) = int(x + 0.5) (:30, :792-804), stored [x][y][z] like the LDT grids here; returns
+// the number of points skipped because they fall outside.
+int64_t orc_dt3d_splat(const double* xyz, int64_t n, uint32_t size, const double* min3, double scale, uint8_t* occ) {
+    const int S = (int)size;
+    std::memset(occ, 0, (size_t)S * S * S);
+    int64_t dropped = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int x = (int)((xyz[3 * i] - min3[0]) * scale + 0.5), y = (int)((xyz[3 * i + 1] - min3[1]) * scale + 0.5),
+                  z = (int)((xyz[3 * i + 2] - min3[2]) * scale + 0.5);
+        if (x < 0 || x >= S || y < 0 || y >= S || z < 0 || z >= S) { dropped++; continue; }
+        occ[((size_t)x * S + y) * S + z] = 1;
+    }
+    return dropped;
+}
+
+// DT3D::Distance (:821-856) over a grid of exact squared cell distances sq[x][y][z].
+void orc_dt3d_lookup(const int32_t* sq, uint32_t size, const double* min3, double scale, const double* q, int64_t n, float* out) {
+    const int S = (int)size;
+    for (int64_t i = 0; i < n; i++) {
+        int x = (int)((q[3 * i] - min3[0]) * scale + 0.5), y = (int)((q[3 * i + 1] - min3[1]) * scale + 0.5),
+            z = (int)((q[3 * i + 2] - min3[2]) * scale + 0.5);
+        float a = 0, b = 0, c = 0;
+        const bool inside = x > -1 && x < S && y > -1 && y < S && z > -1 && z < S;
+        if (x < 0) { a = x; x = 0; } else if (x >= S) { a = x - S + 1; x = S - 1; }
+        if (y < 0) { b = y; y = 0; } else if (y >= S) { b = y - S + 1; y = S - 1; }
+        if (z < 0) { c = z; z = 0; } else if (z >= S) { c = z - S + 1; z = S - 1; }
+        const float g = (float)(std::sqrt((double)sq[((size_t)x * S + y) * S + z]) / scale);
+        out[i] = inside ? g : (float)(std::sqrt((double)(a * a + b * b + c * c)) / scale + g);
+    }
+}
+
 // ---- ICP3D (src/jly_icp3d.cpp:181-295) ---------------------------------------------------------------
 // The ICP of the original Go-ICP code that the reference carries: exact NN, optional trimming to the
 // num = (int)(n * (1 - trim_fraction)) pairs with the smallest squared distance, stop when the summed

@@ -113,6 +113,27 @@ def icp(src, tgt, iters, guess=None, nn_mode=1, threads=0):
     return dict(per_iter_T=per.reshape(iters, 4, 4), T=fin.reshape(4, 4), mse=mse, idx_last=idx)
 
 
+# ---- DT3D convention ------------------------------------------------------------------------------
+def dt3d_box(pts, expand=2.0):
+    """dict(SIZE, scale, min[3], max[3]) by the rule of DT3D::Build (src/jly_3ddt.cpp:732-764)."""
+    p = f64(pts); info = np.empty(8)
+    lib().orc_dt3d_box(_vp(p), C.c_int64(p.shape[0]), C.c_double(expand), _vp(info))
+    return dict(SIZE=int(info[0]), scale=info[1], min=info[2:5].copy(), max=info[5:8].copy())
+
+
+def dt3d_splat(pts, size, mn, scale):
+    p = f64(pts); occ = np.empty((size, size, size), np.uint8)
+    f = lib().orc_dt3d_splat; f.restype = C.c_int64
+    dropped = f(_vp(p), C.c_int64(p.shape[0]), C.c_uint32(size), _vp(f64(mn)), C.c_double(scale), _vp(occ))
+    return occ, int(dropped)
+
+
+def dt3d_lookup(sq, mn, scale, q):
+    sq = np.ascontiguousarray(sq, np.int32); q = f64(q); out = np.empty(q.shape[0], np.float32)
+    lib().orc_dt3d_lookup(_vp(sq), C.c_uint32(sq.shape[0]), _vp(f64(mn)), C.c_double(scale), _vp(q), C.c_int64(q.shape[0]), _vp(out))
+    return out
+
+
 def icp3d_run(model, data, max_iter=10000, err_diff=0.000001, do_trim=True, trim_fraction=0.0, R=None, t=None, threads=0):
     """ICP3D::Run restated (src/jly_icp3d.cpp:181-295). Returns dict(R, t, err, iterations)."""
     model, data = f64(model), f64(data)

@@ -69,6 +69,34 @@ def test_icp_with_guess(oracle, bunny000, bunny045):
     assert np.abs(got["T"] - ref["T"]).max() < 1e-10
 
 
+def test_dt3d_class(gpu_ctx, oracle, bunny000, bunny045):
+    """icp::DT3D (src/jly_3ddt.cpp:727-856): box rule and scale equal to the oracle's, grid and Distance bit-equal to the
+    oracle's DT3D-convention lookup over the exact EDT, inside and outside the grid."""
+    from icp_amd.host import DT3D
+    pts = bunny045.astype(np.float64)
+    dt = DT3D(pts, 2.0)
+    box = oracle.dt3d_box(pts, 2.0)
+    assert dt.SIZE == box["SIZE"] and dt.scale == box["scale"]
+    assert np.array_equal([dt.xMin, dt.yMin, dt.zMin], box["min"]) and np.array_equal([dt.xMax, dt.yMax, dt.zMax], box["max"])
+    occ, dropped = oracle.dt3d_splat(pts, 300, box["min"], box["scale"])
+    sq = oracle.edt_meijster(occ)
+    rng = np.random.default_rng(9)
+    q = np.concatenate([bunny000.astype(np.float64), rng.uniform(box["min"], box["max"], (20000, 3)),
+                        rng.uniform(box["min"] - 0.3, box["max"] + 0.3, (20000, 3))])
+    assert np.array_equal(dt.Distance(q), oracle.dt3d_lookup(sq, box["min"], box["scale"], q))
+    assert dt.Distance(q[:1])[0] == oracle.dt3d_lookup(sq, box["min"], box["scale"], q[:1])[0]
+    # the C ABI underneath: the squared grid itself
+    gpu_ctx.set_target(bunny045)
+    gpu_ctx.edt_build_round(300, box["min"], box["scale"])
+    assert np.array_equal(gpu_ctx.edt_read(), sq)
+    assert gpu_ctx.edt_info()["dropped"] == dropped
+    from icp_amd import IcpxError
+    with pytest.raises(IcpxError):
+        gpu_ctx.edt_lookup(bunny000)       # wrong lookup for a rounded grid
+    gpu_ctx.edt_build(64)                  # back to LDT's convention
+    gpu_ctx.edt_lookup(bunny000)
+
+
 @pytest.mark.parametrize("do_trim,frac,err_diff,max_iter", [(False, 0.0, -1.0, 10), (True, 0.1, -1.0, 10), (True, 0.25, 0.000001, 200)])
 def test_icp3d_class(oracle, bunny000, bunny045, do_trim, frac, err_diff, max_iter):
     """icp::ICP3D (src/jly_icp3d.cpp:181-295) on the GPU against the oracle's restatement, which the CPU suite pins on

@@ -88,3 +88,24 @@ def test_icp3d_restatement_equals_icp3d_run(ref, bunny000, bunny045, do_trim, fr
     assert abs(got["err"] - err) <= 1e-6 * err
     if err_diff > 0:
         assert 2 <= got["iterations"] < max_iter      # the stop test fired
+
+
+def test_dt3d_convention_against_dt3d(ref, bunny000, bunny045):
+    """Box rule and rounded indexing of the oracle's DT3D convention against DT3D itself (src/jly_3ddt.cpp): box and
+    scale bit-equal; zero distance exactly at the voxels DT3D marks; distances within DT3D's approximation error
+    inside the grid and for queries outside it (clamp + overshoot)."""
+    pts = bunny045.astype(np.float64)
+    dt = ref.RefDT3D(pts, 2.0)
+    box = ref.dt3d_box(pts, 2.0)
+    assert box["SIZE"] == dt.size and box["scale"] == dt.scale
+    assert np.array_equal(box["min"], dt.mn) and np.array_equal(box["max"], dt.mx)
+    occ, dropped = ref.dt3d_splat(pts, 300, box["min"], box["scale"])
+    assert dropped == 0
+    sq = ref.edt_meijster(occ)
+    assert np.all(dt.distance(pts) == 0) and np.all(ref.dt3d_lookup(sq, box["min"], box["scale"], pts) == 0)
+    rng = np.random.default_rng(2)
+    inside = rng.uniform(box["min"], box["max"], (20000, 3))
+    far = rng.uniform(box["min"] - 0.2, box["max"] + 0.2, (5000, 3))
+    for q in (bunny000.astype(np.float64), inside, far):
+        mine = ref.dt3d_lookup(sq, box["min"], box["scale"], q); theirs = dt.distance(q)
+        assert np.abs(mine - theirs).max() < 2.0 / box["scale"]
