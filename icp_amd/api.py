@@ -85,6 +85,14 @@ class Context:
         self._ck(self._lib.icpx_nn(self._h, p, n, where, pi, pd))
         return idx, d2
 
+    def knn(self, q, k):
+        """k nearest target points per query (host arrays): idx [n, k] int32, d2 [n, k] float64, ascending."""
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        idx = np.empty((q.shape[0], k), np.int32); d2 = np.empty((q.shape[0], k), np.float64)
+        self._ck(self._lib.icpx_knn(self._h, q.ctypes.data_as(C.c_void_p), q.shape[0], HOST, k, idx.ctypes.data_as(C.c_void_p),
+                                    d2.ctypes.data_as(C.c_void_p)))
+        return idx, d2
+
     def nn_distance(self, q):
         p, where = _ptr(q, np.float32)
         n = q.shape[0]

@@ -156,6 +156,11 @@ void KDTree::get_closest(const double* q, size_t n, int32_t* idx, double* d2) {
     dev->check(icpx_nn(dev->ctx(), q, n, ICPX_HOST, idx, d2));
 }
 
+void KDTree::k_close(const double* q, size_t n, int k, int32_t* idx, double* d2) {
+    ensure_target_on(dev, target);
+    dev->check(icpx_knn(dev->ctx(), q, n, ICPX_HOST, k, idx, d2));
+}
+
 int KDTree::get_closest(const Vector3d& x) {
     int32_t idx = -1;
     get_closest(x.v, 1, &idx, nullptr);
@@ -806,6 +811,9 @@ void* icpxh_kdtree_new(int device, const float* tgt, size_t n) {
 void icpxh_kdtree_free(void* p) { delete (HKd*)p; }
 int icpxh_kdtree_get_closest(void* p, const double* q, size_t n, int32_t* idx, double* d2) {
     return guard([&] { HKd* h = (HKd*)p; if (n == 1) { Vector3d v; v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; idx[0] = h->kd->get_closest(v); if (d2) h->kd->get_closest(q, 1, idx, d2); } else h->kd->get_closest(q, n, idx, d2); });
+}
+int icpxh_kdtree_k_close(void* p, const double* q, size_t n, int k, int32_t* idx, double* d2) {
+    return guard([&] { ((HKd*)p)->kd->k_close(q, n, k, idx, d2); });
 }
 int icpxh_kdtree_distance(void* p, const float* q, size_t n, float* out) {
     return guard([&] { HKd* h = (HKd*)p; if (n == 1) out[0] = h->kd->Distance(q[0], q[1], q[2]); else h->kd->Distance(q, n, out); });

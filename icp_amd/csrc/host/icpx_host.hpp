@@ -114,6 +114,9 @@ class KDTree {              // src/kdtree.cpp:30-152
 public:
     KDTree(const PointCloudTPtr& cloudptr, int _dims = 3, DevicePtr dev = nullptr);
     int get_closest(const Vector3d& x);                       // src/kdtree.cpp:107-122
+    // src/kdtree.cpp:124-150 fills a priority queue with the k nearest; here they come back as indices and
+    // squared distances, nearest first (n queries, row-major n x 3; outputs n x k)
+    void k_close(const double* q, size_t n, int k, int32_t* idx, double* d2 = nullptr);
     float Distance(float x0, float x1, float x2);             // src/kdtree.cpp:91-105
     // batch forms of the two calls above (n queries, row-major n x 3)
     void get_closest(const double* q, size_t n, int32_t* idx, double* d2 = nullptr);

@@ -83,19 +83,52 @@ __global__ void k_pyr_from_flags(const unsigned char* __restrict__ lo, int dx, i
     up[((size_t)(cx >> 1) * uy + (cy >> 1)) * uz + (cz >> 1)] = 1;
 }
 
-struct Best {
+// Search results. Candidates are ordered by (squared distance, index); bound() is the distance beyond which
+// nothing can enter any more.
+struct Best {               // the single nearest
     double d2;
     int idx;
+    __device__ __forceinline__ void init() { d2 = INFINITY; idx = 0x7fffffff; }
+    __device__ __forceinline__ double bound() const { return d2; }
+    __device__ __forceinline__ void offer(double d, int id) {
+        if (d < d2 || (d == d2 && id < idx)) { d2 = d; idx = id; }
+    }
 };
 
-__device__ __forceinline__ void scan_cell(const GridView& g, int cell, double qx, double qy, double qz, Best& b) {
+template <int K>
+struct BestK {              // the K nearest, ascending; unused slots hold (INFINITY, 0x7fffffff)
+    double d2[K];
+    int idx[K];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int k = 0; k < K; k++) { d2[k] = INFINITY; idx[k] = 0x7fffffff; }
+    }
+    __device__ __forceinline__ double bound() const { return d2[K - 1]; }
+    __device__ __forceinline__ void offer(double d, int id) {
+        if (!(d < d2[K - 1] || (d == d2[K - 1] && id < idx[K - 1]))) return;
+        // the pyramid walk revisits the cells of the 3x3x3 block: a point that is already kept must not enter twice
+        bool kept = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) kept |= idx[k] == id;
+        if (kept) return;
+        // one pass of insertion from the back: shift the larger entries up, drop the candidate in its place
+#pragma unroll
+        for (int k = K - 1; k >= 0; k--) {
+            const bool before_prev = k > 0 && (d < d2[k - 1] || (d == d2[k - 1] && id < idx[k - 1]));
+            if (before_prev) { d2[k] = d2[k - 1]; idx[k] = idx[k - 1]; }
+            else { d2[k] = d; idx[k] = id; break; }
+        }
+    }
+};
+
+template <class R>
+__device__ __forceinline__ void scan_cell(const GridView& g, int cell, double qx, double qy, double qz, R& b) {
     const int2 r = g.range[cell];
     for (int k = r.x; k < r.y; k++) {
         const float4 p = g.pts[k];
         const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
         const double d = (dx * dx + dy * dy) + dz * dz;
-        const int id = __float_as_int(p.w);
-        if (d < b.d2 || (d == b.d2 && id < b.idx)) { b.d2 = d; b.idx = id; }
+        b.offer(d, __float_as_int(p.w));
     }
 }
 
@@ -121,8 +154,10 @@ constexpr int NN_LEVELS = MAXLEV + 1;   // per-thread walk state: one word per p
 // nearer children first, skipping empty subtrees and those whose box is farther than the best so far.
 // The walk keeps one word per level (the node being expanded and how many of its children are done),
 // in LDS at `state[level * sstride]`; `loff` are the per-level flag offsets staged in LDS.
-__device__ Best nn_search(const GridView& g, double qx, double qy, double qz, unsigned* state, int sstride, const unsigned* loff) {
-    Best b{INFINITY, 0x7fffffff};
+template <class R>
+__device__ R nn_search_t(const GridView& g, double qx, double qy, double qz, unsigned* state, int sstride, const unsigned* loff) {
+    R b;
+    b.init();
     const int cx = cell_coord((float)qx, g.minx, g.inv, g.dx), cy = cell_coord((float)qy, g.miny, g.inv, g.dy),
               cz = cell_coord((float)qz, g.minz, g.inv, g.dz);
     const double h = (double)g.h;
@@ -136,14 +171,14 @@ __device__ Best nn_search(const GridView& g, double qx, double qy, double qz, un
     const int k0 = max(cz - 1, 0), k1 = min(cz + 1, g.dz - 1);
     for (int i = i0; i <= i1; i++) {
         const double gx = axis_gap2(qx, ox + i * h, ox + (i + 1) * h, margin);
-        if (gx > b.d2) continue;
+        if (gx > b.bound()) continue;
         for (int j = j0; j <= j1; j++) {
             const double gxy = gx + axis_gap2(qy, oy + j * h, oy + (j + 1) * h, margin);
-            if (gxy > b.d2) continue;
+            if (gxy > b.bound()) continue;
             const int row = (i * g.dy + j) * g.dz;
             for (int k = k0; k <= k1; k++) {
                 if (i == cx && j == cy && k == cz) continue;
-                if (gxy + axis_gap2(qz, oz + k * h, oz + (k + 1) * h, margin) > b.d2) continue;
+                if (gxy + axis_gap2(qz, oz + k * h, oz + (k + 1) * h, margin) > b.bound()) continue;
                 scan_cell(g, row + k, qx, qy, qz, b);
             }
         }
@@ -156,7 +191,7 @@ __device__ Best nn_search(const GridView& g, double qx, double qy, double qz, un
     if (cy - 2 >= 0)        { const double t = fmax(qy - (oy + (cy - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
     if (cz + 2 <= g.dz - 1) { const double t = fmax(oz + (cz + 2) * h - qz - margin, 0.0); outside = fmin(outside, t * t); }
     if (cz - 2 >= 0)        { const double t = fmax(qz - (oz + (cz - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
-    if (outside > b.d2) return b;
+    if (outside > b.bound()) return b;
 
     // Pyramid walk. state[l] = coordinates of the node at level l being expanded (3 x 9 bits) | number
     // of its children already handled (4 bits, at bit 27). Level nlev is a virtual root over the (at most
@@ -184,16 +219,41 @@ __device__ Best nn_search(const GridView& g, double qx, double qy, double qz, un
         if (cl == 0) {
             const int2 r = g.range[cidx];
             if (r.y <= r.x) continue;
-            if (box_lb2(qx, qy, qz, ox, oy, oz, cside, ci, cj, ck, margin) > b.d2) continue;
+            if (box_lb2(qx, qy, qz, ox, oy, oz, cside, ci, cj, ck, margin) > b.bound()) continue;
             scan_cell(g, (int)cidx, qx, qy, qz, b);
         } else {
             if (!g.flags[loff[cl] + cidx]) continue;
-            if (box_lb2(qx, qy, qz, ox, oy, oz, cside, ci, cj, ck, margin) > b.d2) continue;
+            if (box_lb2(qx, qy, qz, ox, oy, oz, cside, ci, cj, ck, margin) > b.bound()) continue;
             l = cl;
             state[l * sstride] = ((unsigned)ci << 18) | ((unsigned)cj << 9) | (unsigned)ck;
         }
     }
     return b;
+}
+
+__device__ Best nn_search(const GridView& g, double qx, double qy, double qz, unsigned* state, int sstride, const unsigned* loff) {
+    return nn_search_t<Best>(g, qx, qy, qz, state, sstride, loff);
+}
+
+// K nearest target points of every query, ascending by (squared distance, index); slots beyond the number
+// of target points get index -1 and an infinite distance.
+template <int K>
+__global__ __launch_bounds__(256) void k_knn(GridView g, const double* __restrict__ q, size_t n, int kout, int* __restrict__ idx,
+                                             double* __restrict__ d2) {
+    __shared__ unsigned stk[NN_LEVELS * 256];
+    __shared__ unsigned s_loff[MAXLEV];
+    if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
+    __syncthreads();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const BestK<K> b = nn_search_t<BestK<K>>(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], stk + threadIdx.x, 256, s_loff);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (k < kout) {
+            if (idx) idx[i * kout + k] = b.idx[k] == 0x7fffffff ? -1 : b.idx[k];
+            if (d2) d2[i * kout + k] = b.d2[k];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_nn(GridView g, const double* __restrict__ q, size_t n, int* __restrict__ idx, double* __restrict__ d2) {
@@ -471,6 +531,36 @@ extern "C" int icpx_nn(icpx_ctx* ctx, const double* q_xyz, size_t n, int where, 
     if (where == ICPX_HOST) {
         if (idx) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(idx, didx, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         if (d2) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(d2, dd2, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+extern "C" int icpx_knn(icpx_ctx* ctx, const double* q_xyz, size_t n, int where, int k, int32_t* idx, double* d2) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->grid_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_knn: no target cloud (call icpx_set_target first)");
+    if (k < 1 || k > ICPX_MAX_KNN) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_knn: k must be in [1, %d]", ICPX_MAX_KNN);
+    if (n == 0) return ICPX_OK;
+    if (!q_xyz) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_knn: queries are NULL");
+    ICPX_TRY(icpx_bind(ctx));
+    const double* dq = q_xyz; int* didx = idx; double* dd2 = d2;
+    if (where == ICPX_HOST) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->scratch_q, n * 3 * sizeof(double)));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, q_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        dq = ctx->scratch_q.as<double>();
+        if (idx) { ICPX_TRY(icpx_reserve(ctx, ctx->scratch_idx, n * k * sizeof(int))); didx = ctx->scratch_idx.as<int>(); }
+        if (d2) { ICPX_TRY(icpx_reserve(ctx, ctx->scratch_d2, n * k * sizeof(double))); dd2 = ctx->scratch_d2.as<double>(); }
+    }
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (k == 1) hipLaunchKernelGGL(k_knn<1>, grid, block, 0, ctx->stream, view_of(ctx), dq, n, k, didx, dd2);
+    else if (k == 2) hipLaunchKernelGGL(k_knn<2>, grid, block, 0, ctx->stream, view_of(ctx), dq, n, k, didx, dd2);
+    else if (k <= 4) hipLaunchKernelGGL(k_knn<4>, grid, block, 0, ctx->stream, view_of(ctx), dq, n, k, didx, dd2);
+    else if (k <= 5) hipLaunchKernelGGL(k_knn<5>, grid, block, 0, ctx->stream, view_of(ctx), dq, n, k, didx, dd2);
+    else hipLaunchKernelGGL(k_knn<8>, grid, block, 0, ctx->stream, view_of(ctx), dq, n, k, didx, dd2);
+    ICPX_TRY(icpx_launch_check(ctx, "k_knn"));
+    if (where == ICPX_HOST) {
+        if (idx) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(idx, didx, n * k * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        if (d2) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(d2, dd2, n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICPX_OK;

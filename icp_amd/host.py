@@ -26,6 +26,7 @@ def _lib():
         for name in ("icpxh_kdtree_free", "icpxh_ldt_free", "icpxh_icp_free", "icpxh_goicp_free"):
             getattr(lib, name).argtypes = [C.c_void_p]; getattr(lib, name).restype = None
         lib.icpxh_kdtree_get_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.icpxh_kdtree_k_close.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         lib.icpxh_kdtree_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.icpxh_ldt_info.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         lib.icpxh_ldt_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -128,6 +129,12 @@ class KDTree:
         idx = np.empty(q.shape[0], np.int32); d2 = np.empty(q.shape[0], np.float64) if want_d2 else None
         _ck(_lib().icpxh_kdtree_get_closest(self._h, _vp(q), q.shape[0], _vp(idx), _vp(d2)))
         return (idx, d2) if want_d2 else idx
+
+    def k_close(self, q, k):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        idx = np.empty((q.shape[0], k), np.int32); d2 = np.empty((q.shape[0], k), np.float64)
+        _ck(_lib().icpxh_kdtree_k_close(self._h, _vp(q), q.shape[0], k, _vp(idx), _vp(d2)))
+        return idx, d2
 
     def Distance(self, q):
         q = _f32(q).reshape(-1, 3); out = np.empty(q.shape[0], np.float32)

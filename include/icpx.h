@@ -76,6 +76,13 @@ int icpx_set_target(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_byt
  * Ties resolve to the lowest target index. idx and d2 may each be NULL; they live where q lives. */
 int icpx_nn(icpx_ctx* ctx, const double* q_xyz, size_t n, int where, int32_t* idx, double* d2);
 
+/* Replaces KDTree::k_close(p, k, 1, Q) (src/kdtree.cpp:124-150): the k nearest target points of every query,
+ * ascending by squared distance (the reference's priority queue pops them in descending order), equal
+ * distances by ascending index. idx: n x k int32, d2: n x k doubles, either may be NULL; with fewer than k
+ * target points the remaining slots get index -1 and an infinite distance. 1 <= k <= ICPX_MAX_KNN. */
+#define ICPX_MAX_KNN 8
+int icpx_knn(icpx_ctx* ctx, const double* q_xyz, size_t n, int where, int k, int32_t* idx, double* d2);
+
 /* Replaces KDTree::Distance (src/kdtree.cpp:91-105): float queries, widened to double; returns
  * (float)sqrt(min squared distance). n x 3 floats in, n floats out. */
 int icpx_nn_distance(icpx_ctx* ctx, const float* q_xyz, size_t n, int where, float* dist);

@@ -75,6 +75,26 @@ struct KdTree {
         build(rc, mid + 1, r, dep + 1);
     }
 
+    // k_close as written: visit the near child, then this node (push while the queue is short, else replace the
+    // largest if strictly smaller), then the far child if the splitting plane is closer than the largest kept
+    // (always, while the queue is short).
+    void search_k(const double* p, int64_t o, int k, std::priority_queue<double>& Q) const {
+        if ((size_t)o >= used.size() || !used[o]) return;
+        const KdNode& nd = heap[o];
+        int64_t lc = o << 1, rc = lc | 1;
+        if (p[nd.dim] > nd.f[nd.dim]) std::swap(lc, rc);
+        const double cur = sqdist(p, nd.f);
+        if ((size_t)lc < used.size() && used[lc]) search_k(p, lc, k, Q);
+        bool go;
+        if ((int)Q.size() < k) { Q.push(cur); go = true; }
+        else {
+            if (cur < Q.top()) { Q.pop(); Q.push(cur); }
+            const double dd = p[nd.dim] - nd.f[nd.dim];
+            go = dd * dd < Q.top();
+        }
+        if (go && (size_t)rc < used.size() && used[rc]) search_k(p, rc, k, Q);
+    }
+
     struct Best { double d2; int index; bool have; };
 
     void search(const double* p, int64_t o, Best& b) const {
@@ -263,6 +283,43 @@ void orc_nn_brute(const double* q, int64_t n, const float* tgt, int64_t m, int32
         }
         if (idx) idx[i] = bi;
         if (d2) d2[i] = best;
+    }
+}
+
+// Brute-force k nearest neighbours, ascending by (squared distance, index); slots beyond m get (-1, inf).
+void orc_knn_brute(const double* q, int64_t n, const float* tgt, int64_t m, int k, int32_t* idx, double* d2, int threads) {
+    std::vector<double> t(3 * m);
+    for (int64_t j = 0; j < 3 * m; j++) t[j] = (double)tgt[j];
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        std::vector<double> bd(k, INFINITY);
+        std::vector<int32_t> bi(k, -1);
+        for (int64_t j = 0; j < m; j++) {
+            const double d = sqdist(q + 3 * i, t.data() + 3 * j);
+            if (!(d < bd[k - 1])) continue;          // equal distance: the earlier (lower) index stays
+            int s = k - 1;
+            while (s > 0 && d < bd[s - 1]) { bd[s] = bd[s - 1]; bi[s] = bi[s - 1]; s--; }
+            bd[s] = d; bi[s] = (int32_t)j;
+        }
+        for (int s = 0; s < k; s++) { idx[i * k + s] = bi[s]; d2[i * k + s] = bd[s]; }
+    }
+}
+
+// KDTree::k_close (src/kdtree.cpp:124-150) over n double queries: squared distances of the k nearest,
+// ascending (the reference's priority queue holds them with the largest on top). Indices are not returned:
+// among equal distances the reference keeps whichever node its traversal meets first.
+void orc_kdtree_knn_d2(void* h, const double* q, int64_t n, int k, double* d2, int threads) {
+    const KdTree* t = (const KdTree*)h;
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        std::priority_queue<double> Q;
+        t->search_k(q + 3 * i, 1, k, Q);
+        for (int s = k - 1; s >= 0; s--) {
+            if ((int)Q.size() > s) { d2[i * k + s] = Q.top(); Q.pop(); }
+            else d2[i * k + s] = INFINITY;
+        }
     }
 }
 

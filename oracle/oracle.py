@@ -65,6 +65,15 @@ def nn_brute(q, tgt, threads=0):
     return idx, d2
 
 
+def knn_brute(q, tgt, k, threads=0):
+    """k nearest by (squared distance, index): idx [n, k] int32 (-1 beyond the cloud), d2 [n, k]."""
+    q, tgt = f64(q), f32(tgt)
+    n, m = q.shape[0], tgt.shape[0]
+    idx = np.empty((n, k), np.int32); d2 = np.empty((n, k), np.float64)
+    lib().orc_knn_brute(_vp(q), C.c_int64(n), _vp(tgt), C.c_int64(m), C.c_int(k), _vp(idx), _vp(d2), C.c_int(threads))
+    return idx, d2
+
+
 class KdTree:
     def __init__(self, tgt):
         self.tgt = f32(tgt)
@@ -75,6 +84,13 @@ class KdTree:
         idx = np.empty(n, np.int32); d2 = np.empty(n, np.float64)
         lib().orc_kdtree_nn(self.h, _vp(q), C.c_int64(n), _vp(idx), _vp(d2), C.c_int(threads))
         return idx, d2
+
+    def knn_d2(self, q, k, threads=0):
+        """Squared distances of KDTree::k_close's k results, ascending."""
+        q = f64(q); n = q.shape[0]
+        d2 = np.empty((n, k), np.float64)
+        lib().orc_kdtree_knn_d2(self.h, _vp(q), C.c_int64(n), C.c_int(k), _vp(d2), C.c_int(threads))
+        return d2
 
     def distance(self, q, threads=0):
         q = f32(q); n = q.shape[0]
@@ -238,6 +254,13 @@ def ref_nanoflann_nn(tgt, q):
     tgt, q = f64(tgt), f64(q)
     idx = np.empty(q.shape[0], np.int64); d2 = np.empty(q.shape[0], np.float64)
     ref().ref_nanoflann_nn(_vp(tgt), C.c_int64(tgt.shape[0]), _vp(q), C.c_int64(q.shape[0]), _vp(idx), _vp(d2))
+    return idx, d2
+
+
+def ref_nanoflann_knn(tgt, q, k):
+    tgt, q = f64(tgt), f64(q)
+    idx = np.empty((q.shape[0], k), np.int64); d2 = np.empty((q.shape[0], k), np.float64)
+    ref().ref_nanoflann_knn(_vp(tgt), C.c_int64(tgt.shape[0]), _vp(q), C.c_int64(q.shape[0]), C.c_int(k), _vp(idx), _vp(d2))
     return idx, d2
 
 

@@ -30,6 +30,21 @@ void ref_nanoflann_nn(const double* tgt, int64_t m, const double* q, int64_t n, 
     }
 }
 
+// nanoflann knnSearch with k results per query (ascending squared distances).
+void ref_nanoflann_knn(const double* tgt, int64_t m, const double* q, int64_t n, int k, int64_t* idx, double* d2) {
+    PointCloud<double> pc;
+    pc.pts.resize(m);
+    for (int64_t i = 0; i < m; i++) { pc.pts[i].x = tgt[3 * i]; pc.pts[i].y = tgt[3 * i + 1]; pc.pts[i].z = tgt[3 * i + 2]; }
+    typedef KDTreeSingleIndexAdaptor<L2_Simple_Adaptor<double, PointCloud<double> >, PointCloud<double>, 3> Tree;
+    Tree tree(3, pc, KDTreeSingleIndexAdaptorParams(10));
+    tree.buildIndex();
+    std::vector<size_t> ri(k);
+    for (int64_t i = 0; i < n; i++) {
+        tree.knnSearch(q + 3 * i, (size_t)k, ri.data(), d2 + i * k);
+        for (int s = 0; s < k; s++) idx[i * k + s] = (int64_t)ri[s];
+    }
+}
+
 // Matrix::svd (src/matrix.cpp:582-810): A = U diag(W) V^T, all 3x3 row-major.
 void ref_matrix_svd3(const double* A9, double* U9, double* W3, double* V9) {
     Matrix A(3, 3, A9), U, W, V;

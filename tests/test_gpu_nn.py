@@ -96,3 +96,32 @@ def test_nn_empty_and_errors(gpu_ctx, bunny045):
     gpu_ctx.set_target(bunny045)
     idx, d2 = gpu_ctx.nn(np.zeros((0, 3)))
     assert idx.shape == (0,)
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 8])
+def test_knn_against_brute_force(gpu_ctx, oracle, bunny000, bunny045, k):
+    """icpx_knn (KDTree::k_close, src/kdtree.cpp:124-150): indices and squared distances of the k nearest, ordered by
+    (distance, index), bit-equal to brute force for near, displaced and far queries."""
+    gpu_ctx.set_target(bunny045)
+    rng = np.random.default_rng(k)
+    q = np.concatenate([bunny000[::5].astype(np.float64), bunny045[::9].astype(np.float64),          # incl. exact hits
+                        bunny000[::11].astype(np.float64) + rng.normal(0, 0.01, (len(bunny000[::11]), 3)),
+                        rng.uniform(-0.5, 0.5, (500, 3))])
+    idx, d2 = gpu_ctx.knn(q, k)
+    ridx, rd2 = oracle.knn_brute(q, bunny045, k)
+    assert np.array_equal(d2, rd2) and np.array_equal(idx, ridx)
+    assert np.array_equal(idx[:, 0], gpu_ctx.nn(q)[0])
+
+
+def test_knn_small_cloud_and_limits(gpu_ctx, oracle):
+    from icp_amd import IcpxError
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], np.float32)
+    gpu_ctx.set_target(pts)
+    q = np.array([[0.1, 0.1, 0.0], [5.0, 5.0, 5.0]])
+    idx, d2 = gpu_ctx.knn(q, 5)
+    ridx, rd2 = oracle.knn_brute(q, pts, 5)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.all(idx[:, 3:] == -1) and np.all(np.isinf(d2[:, 3:]))
+    with pytest.raises(IcpxError):
+        gpu_ctx.knn(q, 9)
+    with pytest.raises(IcpxError):
+        gpu_ctx.knn(q, 0)

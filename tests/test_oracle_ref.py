@@ -109,3 +109,17 @@ def test_dt3d_convention_against_dt3d(ref, bunny000, bunny045):
     for q in (bunny000.astype(np.float64), inside, far):
         mine = ref.dt3d_lookup(sq, box["min"], box["scale"], q); theirs = dt.distance(q)
         assert np.abs(mine - theirs).max() < 2.0 / box["scale"]
+
+
+def test_knn_distances_equal_nanoflann_and_k_close(ref, bunny000, bunny045):
+    """k = 5 nearest: brute force, the restated KDTree::k_close (src/kdtree.cpp:124-150) and nanoflann's knnSearch
+    return bit-equal squared distances; indices agree wherever the k + 1 nearest distances are distinct."""
+    q = bunny000[::7].astype(np.float64) + 1e-4
+    bi, bd = ref.knn_brute(q, bunny045, 5)
+    kd = ref.KdTree(bunny045).knn_d2(q, 5)
+    ni, nd = ref.ref_nanoflann_knn(bunny045.astype(np.float64), q, 5)
+    assert np.array_equal(bd, kd) and np.array_equal(bd, nd)
+    _, bd6 = ref.knn_brute(q, bunny045, 6)
+    distinct = np.all(np.diff(bd6, axis=1) > 0, axis=1)
+    assert distinct.mean() > 0.9 and np.array_equal(bi[distinct], ni[distinct].astype(np.int32))
+    assert np.array_equal(bd[:, 0], ref.nn_brute(q, bunny045)[1])
