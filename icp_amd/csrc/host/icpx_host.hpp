@@ -268,7 +268,11 @@ public:
     bool run_bnb = true;          // false: stop after the initial ICP, like the committed early return (src/GoIcp.cpp:189)
     bool batched = true;          // true: the 2 x 8 inner searches of one rotation parent advance in lock-step, one launch per step
     bool parity_sums = false;     // true: bounds are the reference's sequential float sums of the per-point distances
-    int frontier_width = 1;       // translation parents popped per inner search and step (batched mode)
+    // Translation parents popped per inner search and step (batched mode). The reference's inner search returns at
+    // the first evaluated child whose lower bound is within sseThresh of the best error (src/GoIcp.cpp:445-449), so
+    // the expansion order decides where it stops: 1 keeps the reference's order, larger values are faster per cube
+    // but may end with a different (still threshold-accepted) result.
+    int frontier_width = 1;
     long long max_rot_pops = 0;   // 0 = unlimited
     Collective comm;              // world > 1: every bound batch is split over the ranks
     // statistics
