@@ -93,6 +93,7 @@ extern "C" void icpx_destroy(icpx_ctx* ctx) {
                       &ctx->bnb_mindis};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
+    if (ctx->bnb_pin) (void)hipHostFree(ctx->bnb_pin);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -13,8 +13,9 @@
 #include "icpx_ctx.h"
 #include "icpx_edt_dev.h"
 
+#include <algorithm>
 #include <cmath>
-
+#include <cstring>
 
 namespace {
 
@@ -162,6 +163,18 @@ extern "C" int icpx_goicp_read_maxrotdist(icpx_ctx* ctx, float* out) {
     return ICPX_OK;
 }
 
+// Grow-only pinned host buffer: copies through it are truly asynchronous and take one DMA each, where a
+// pageable source or destination is staged by the runtime in several steps.
+static int bnb_pin_reserve(icpx_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->bnb_pin_cap) return ICPX_OK;
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->bnb_pin) { ICPX_CHECK_HIP(ctx, hipHostFree(ctx->bnb_pin)); ctx->bnb_pin = nullptr; ctx->bnb_pin_cap = 0; }
+    const size_t want = std::max<size_t>(bytes * 2, 1 << 16);
+    ICPX_CHECK_HIP(ctx, hipHostMalloc(&ctx->bnb_pin, want, hipHostMallocDefault));
+    ctx->bnb_pin_cap = want;
+    return ICPX_OK;
+}
+
 static int bnb_enqueue(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev, float* mindis_dev) {
     if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_eval: no EDT has been built");
     if (ctx->nd == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_eval: no data cloud (call icpx_goicp_set_data first)");
@@ -176,9 +189,14 @@ static int bnb_enqueue(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems,
     if (nsplit < 1) nsplit = 1;
     ICPX_TRY(icpx_reserve(ctx, ctx->bnb_items, nitems * sizeof(icpx_bnb_item)));
     ICPX_TRY(icpx_reserve(ctx, ctx->bnb_partials, nitems * nsplit * 2 * sizeof(double)));
-    // The item list is copied from pageable host memory: hipMemcpyAsync returns only after the source
-    // has been staged, so the caller may reuse `items` as soon as this function returns.
-    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->bnb_items.p, items, nitems * sizeof(icpx_bnb_item), hipMemcpyHostToDevice, ctx->stream));
+    // The item list goes through the pinned buffer (front part; the results come back into the part behind
+    // it), so the caller may reuse `items` as soon as this function returns. A previous batch that is still
+    // in flight on the stream would read the same staging area: batches are serialised here.
+    const size_t items_bytes = nitems * sizeof(icpx_bnb_item);
+    ICPX_TRY(bnb_pin_reserve(ctx, items_bytes + 2 * nitems * sizeof(double)));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(ctx->bnb_pin, items, items_bytes);
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->bnb_items.p, ctx->bnb_pin, items_bytes, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nitems, (unsigned)nsplit), dim3(256), 0, ctx->stream, edt_view(ctx),
                        ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), ctx->bnb_items.as<icpx_bnb_item>(), nsplit,
                        ctx->bnb_partials.as<double>(), mindis_dev);
@@ -199,11 +217,13 @@ extern "C" int icpx_bnb_eval(icpx_ctx* ctx, const icpx_bnb_item* items, size_t n
         md = ctx->bnb_mindis.as<float>();
     }
     ICPX_TRY(bnb_enqueue(ctx, items, nitems, ctx->bnb_out.as<double>(), md));
-    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ub, ctx->bnb_out.p, nitems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(lb, ctx->bnb_out.as<double>() + nitems, nitems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double* res = reinterpret_cast<double*>(static_cast<char*>(ctx->bnb_pin) + nitems * sizeof(icpx_bnb_item));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(res, ctx->bnb_out.p, 2 * nitems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (mindis_opt)
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(mindis_opt, md, nitems * ctx->nd * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(ub, res, nitems * sizeof(double));
+    std::memcpy(lb, res + nitems, nitems * sizeof(double));
     return ICPX_OK;
 }
 

@@ -196,7 +196,8 @@ typedef struct icpx_bnb_item {
 int icpx_bnb_eval(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* ub, double* lb, float* mindis_opt);
 
 /* Enqueue-only variant for multi-GPU use: out_dev is DEVICE memory, 2 * nitems doubles laid out
- * [ub_0 .. ub_{n-1}, lb_0 .. lb_{n-1}]. items is host memory and is copied before the call returns. */
+ * [ub_0 .. ub_{n-1}, lb_0 .. lb_{n-1}]. items is host memory and is copied before the call returns (through
+ * one pinned staging area per context: the call first waits for earlier work on the context's stream). */
 int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev);
 
 /* Replaces the SSE loop of GoIcp::runICP (src/GoIcp.cpp:113-135) and the initial error of OuterBnB
