@@ -148,11 +148,14 @@ int icpx_stage_points4(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_
     return icpx_launch_check(ctx, "k_pack_points4");
 }
 
-// Per-block min / max of float4 points -> partial[block] = {min xyz, max xyz}.
+// Per-block min / max of float4 points -> partial[block] = {min xyz, max xyz, 1 if a coordinate is NaN or
+// infinite (such a point would be filed under an arbitrary cell and poison every distance it meets)}.
 __global__ __launch_bounds__(256) void k_bbox_partial(const float4* __restrict__ pts, size_t n, float* __restrict__ partial) {
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    bool bad = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float4 p = pts[i];
+        bad |= !(fabsf(p.x) <= FLT_MAX && fabsf(p.y) <= FLT_MAX && fabsf(p.z) <= FLT_MAX);
         mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
         mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
     }
@@ -166,24 +169,30 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const float4* __restrict__
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) for (int c = 0; c < 3; c++) { sm[c][wave] = mn[c]; sm[3 + c][wave] = mx[c]; }
     __syncthreads();
+    const int any_bad = __syncthreads_or(bad);
     if (threadIdx.x < 6) {
         float v = sm[threadIdx.x][0];
         for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? fminf(v, sm[threadIdx.x][w]) : fmaxf(v, sm[threadIdx.x][w]);
-        partial[blockIdx.x * 6 + threadIdx.x] = v;
+        partial[blockIdx.x * 7 + threadIdx.x] = v;
     }
+    if (threadIdx.x == 6) partial[blockIdx.x * 7 + 6] = any_bad ? 1.f : 0.f;
 }
 
 static int device_bbox4(icpx_ctx* ctx, const float4* pts, size_t n, float mn[3], float mx[3]) {
     const int blocks = (int)std::min<size_t>(1024, (n + 255) / 256);
-    ICPX_TRY(icpx_reserve(ctx, ctx->partials, sizeof(float) * 6 * 1024));
+    ICPX_TRY(icpx_reserve(ctx, ctx->partials, sizeof(float) * 7 * 1024));
     hipLaunchKernelGGL(k_bbox_partial, dim3(blocks), dim3(256), 0, ctx->stream, pts, n, ctx->partials.as<float>());
     ICPX_TRY(icpx_launch_check(ctx, "k_bbox_partial"));
-    std::vector<float> h(6 * blocks);
-    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(h.data(), ctx->partials.p, sizeof(float) * 6 * blocks, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<float> h(7 * blocks);
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(h.data(), ctx->partials.p, sizeof(float) * 7 * blocks, hipMemcpyDeviceToHost, ctx->stream));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int c = 0; c < 3; c++) { mn[c] = h[c]; mx[c] = h[3 + c]; }
-    for (int b = 1; b < blocks; b++)
-        for (int c = 0; c < 3; c++) { mn[c] = std::min(mn[c], h[6 * b + c]); mx[c] = std::max(mx[c], h[6 * b + 3 + c]); }
+    bool bad = h[6] != 0.f;
+    for (int b = 1; b < blocks; b++) {
+        for (int c = 0; c < 3; c++) { mn[c] = std::min(mn[c], h[7 * b + c]); mx[c] = std::max(mx[c], h[7 * b + 3 + c]); }
+        bad = bad || h[7 * b + 6] != 0.f;
+    }
+    if (bad) ICPX_FAIL(ctx, ICPX_EINVAL, "the cloud holds NaN or infinite coordinates (the reference's loader drops such points, src/main.cpp:35-51)");
     return ICPX_OK;
 }
 

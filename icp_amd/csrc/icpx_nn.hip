@@ -307,7 +307,9 @@ __global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __re
         }
         const Best b = nn_search(g, p[0], p[1], p[2], stk + threadIdx.x, 256, s_loff);
         if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
-        const double q0 = (double)tgt_xyz[3 * (size_t)b.idx], q1 = (double)tgt_xyz[3 * (size_t)b.idx + 1], q2 = (double)tgt_xyz[3 * (size_t)b.idx + 2];
+        // a NaN in T leaves no candidate: read point 0 then (the sums are NaN anyway) instead of an invalid index
+        const size_t j = b.idx == 0x7fffffff ? 0 : (size_t)b.idx;
+        const double q0 = (double)tgt_xyz[3 * j], q1 = (double)tgt_xyz[3 * j + 1], q2 = (double)tgt_xyz[3 * j + 2];
         acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
         acc[3] += q0; acc[4] += q1; acc[5] += q2;
         acc[6] += p[0] * q0; acc[7] += p[0] * q1; acc[8] += p[0] * q2;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256) void k_icp_trim_sums(const unsigned* __restric
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < keep; r += (size_t)gridDim.x * blockDim.x) {
         const size_t o = order[r];
         const double p0 = pbuf[3 * o], p1 = pbuf[3 * o + 1], p2 = pbuf[3 * o + 2];
-        const size_t j = (size_t)idx[o];
+        const size_t j = idx[o] == 0x7fffffff ? 0 : (size_t)idx[o];   // no candidate (NaN transform): see k_icp_step
         const double q0 = (double)tgt_xyz[3 * j], q1 = (double)tgt_xyz[3 * j + 1], q2 = (double)tgt_xyz[3 * j + 2];
         acc[0] += p0; acc[1] += p1; acc[2] += p2;
         acc[3] += q0; acc[4] += q1; acc[5] += q2;

@@ -98,6 +98,34 @@ def test_nn_empty_and_errors(gpu_ctx, bunny045):
     assert idx.shape == (0,)
 
 
+def test_non_finite_input_is_refused_or_harmless(gpu_ctx, oracle, bunny000, bunny045):
+    """A cloud with a NaN or infinite coordinate is refused when it is handed over (the reference's loader never
+    produces one: it drops non-finite rows, src/main.cpp:35-51); NaN queries and a NaN transform do not fault."""
+    from icp_amd import IcpxError
+    for bad in (np.nan, np.inf, -np.inf):
+        cloud = bunny045.copy()
+        cloud[len(cloud) // 2, 1] = bad
+        with pytest.raises(IcpxError, match="NaN or infinite"):
+            gpu_ctx.set_target(cloud)
+        with pytest.raises(IcpxError, match="NaN or infinite"):
+            gpu_ctx.set_source(cloud)
+        with pytest.raises(IcpxError, match="NaN or infinite"):
+            gpu_ctx.goicp_set_data(cloud)
+    gpu_ctx.set_target(bunny045)
+    q = bunny000[:100].astype(np.float64).copy()
+    q[7] = np.nan
+    idx, d2 = gpu_ctx.nn(q)
+    ridx, rd2 = oracle.nn_brute(np.delete(q, 7, axis=0), bunny045)
+    assert np.array_equal(np.delete(idx, 7), ridx)
+    gpu_ctx.set_source(bunny000)
+    T = np.eye(4); T[0, 3] = np.nan
+    sums = gpu_ctx.icp_step(T)
+    assert np.isnan(np.asarray(sums)).any()
+    # the context is still usable afterwards
+    idx2, _ = gpu_ctx.nn(bunny000[:100].astype(np.float64))
+    assert np.array_equal(idx2, oracle.nn_brute(bunny000[:100].astype(np.float64), bunny045)[0])
+
+
 @pytest.mark.parametrize("k", [1, 2, 5, 8])
 def test_knn_against_brute_force(gpu_ctx, oracle, bunny000, bunny045, k):
     """icpx_knn (KDTree::k_close, src/kdtree.cpp:124-150): indices and squared distances of the k nearest, ordered by
