@@ -155,14 +155,13 @@ __global__ __launch_bounds__(1024) void k_edt_census(u64* __restrict__ bits, int
     if (lane < 8) next_counters[lane] = 0ull;
 }
 
-// floor(N / D) for 0 <= N < 2^23, 1 <= D < 2^12, exact whenever the quotient is below 2^12 (the callers
-// only use quotients below div <= 1023; larger ones just have to stay >= div, and the estimate is off by
-// at most 2 there). One float reciprocal, one multiply, one correction step in each direction.
+// floor(N / D) for 0 <= N < 2^22 and even 2 <= D <= 2046: exact whenever the quotient is below 1400, at
+// least 1023 otherwise (the callers only tell quotients below div <= 1023 apart). (2N + 1) / (2D) has the
+// same floor as N / D and lies at least 1 / (2D) away from every integer, which is more than the error of
+// the 1-ulp reciprocal and the rounded product for quotients in that range, so truncating the float
+// product is enough; tools/check_floordiv.hip runs through all N and D on the GPU.
 __device__ __forceinline__ int floordiv_pos(int N, int D) {
-    int k = (int)((float)N * __builtin_amdgcn_rcpf((float)D));
-    const int r = N - __mul24(k, D);      // |k| < 2^13 wherever the result matters, D < 2^12
-    k += (r >= D) - (r < 0);
-    return k;
+    return (int)((float)(2 * N + 1) * __builtin_amdgcn_rcpf((float)(2 * D)));
 }
 
 __device__ __forceinline__ int bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
