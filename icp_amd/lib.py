@@ -62,7 +62,8 @@ ICPX_SYMBOLS = {
 
 
 def _load(name):
-    path = os.path.join(_HERE, name)
+    # ICPX_LIB_DIR: load the libraries from another directory (A/B runs of two builds, tools/edt_ab.py)
+    path = os.path.join(os.environ.get("ICPX_LIB_DIR", _HERE), name)
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: build it with `make -C icp_amd/csrc` "
                           f"(or __graft_entry__.build()); icp_amd has no CPU fallback")
