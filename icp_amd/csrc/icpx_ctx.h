@@ -48,6 +48,7 @@ struct icpx_ctx {
     // ---- source cloud (ICP) ----------------------------------------------------------------------
     size_t ns = 0;
     DevBuf src_pts;          // ns x float4 {x, y, z, bits(original index)}, spatially sorted
+    DevBuf nn_seed;          // ns int: target index each source point (sorted position) was paired with by the last ICP pass, -1 = none
     DevBuf partials;         // per-block partial sums
     DevBuf sums;             // ICPX_NSUMS doubles
     DevBuf scratch_q, scratch_idx, scratch_d2, scratch_f;   // staging for host-pointer calls

@@ -166,8 +166,6 @@ __device__ __forceinline__ int floordiv_pos(int N, int D) {
 
 __device__ __forceinline__ int bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// (a - b)^2 + c for |a - b| < 2^23 (one subtract and one 24-bit multiply-add)
-__device__ __forceinline__ int sqdist(int a, int b, int c) { return __mul24(a - b, a - b) + c; }
 
 // Waits for outstanding global loads only. Placed inside the rarely taken spill branches so that their
 // loads are retired before control rejoins the hot path; otherwise the join point gets a wait for every

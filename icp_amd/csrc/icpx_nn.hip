@@ -24,14 +24,15 @@ namespace {
 
 constexpr int MAXLEV = 11;
 
-// Level 0 is the cell grid itself; level l >= 1 halves every dimension (rounding up) and keeps one byte
-// per cell: non-zero when any point lies below it. The search uses the pyramid to skip empty space.
+// Level 0 is the cell grid itself; level l >= 1 halves every dimension (rounding up), up to a single root
+// node, and keeps one byte per node: bit (di << 2 | dj << 1 | dk) is set when child (2i + di, 2j + dj,
+// 2k + dk) of the level below holds a point. The search uses the pyramid to skip empty space.
 struct GridView {
     int dx, dy, dz;
     float minx, miny, minz, h, inv;
     const int2* __restrict__ range;
     const float4* __restrict__ pts;
-    const unsigned char* __restrict__ flags;   // all levels >= 1, level l at flags + loff[l]
+    const unsigned char* __restrict__ flags;   // child masks of all levels >= 1, level l at flags + loff[l]
     const unsigned* __restrict__ loff;          // MAXLEV offsets into flags (device memory)
     int nlev;                                   // number of levels including level 0
 };
@@ -66,21 +67,27 @@ __global__ void k_gather_pts(const float4* __restrict__ src, const unsigned* __r
     if (i < n) dst[i] = src[order[i]];
 }
 
-__global__ void k_pyr_from_cells(const int2* __restrict__ range, int dx, int dy, int dz, unsigned char* __restrict__ up, int ux, int uy, int uz) {
+// Sets the bit of child (cx, cy, cz) in the mask byte of its parent; `up` is the 4-byte aligned first word of
+// the parent level (bytes have no atomics: the OR goes to the word that holds the byte).
+__device__ __forceinline__ void pyr_mark(unsigned* __restrict__ up, int cx, int cy, int cz, int uy, int uz) {
+    const size_t parent = ((size_t)(cx >> 1) * uy + (cy >> 1)) * uz + (cz >> 1);
+    const unsigned bit = (unsigned)(((cx & 1) << 2) | ((cy & 1) << 1) | (cz & 1));
+    atomicOr(up + (parent >> 2), (1u << bit) << (8 * (parent & 3)));
+}
+
+__global__ void k_pyr_from_cells(const int2* __restrict__ range, int dx, int dy, int dz, unsigned* __restrict__ up, int uy, int uz) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)dx * dy * dz) return;
     const int2 r = range[i];
     if (r.y <= r.x) return;
-    const int cz = (int)(i % dz), cy = (int)((i / dz) % dy), cx = (int)(i / ((size_t)dz * dy));
-    up[((size_t)(cx >> 1) * uy + (cy >> 1)) * uz + (cz >> 1)] = 1;
+    pyr_mark(up, (int)(i / ((size_t)dz * dy)), (int)((i / dz) % dy), (int)(i % dz), uy, uz);
 }
 
-__global__ void k_pyr_from_flags(const unsigned char* __restrict__ lo, int dx, int dy, int dz, unsigned char* __restrict__ up, int ux, int uy, int uz) {
+__global__ void k_pyr_from_masks(const unsigned char* __restrict__ lo, int dx, int dy, int dz, unsigned* __restrict__ up, int uy, int uz) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)dx * dy * dz) return;
     if (!lo[i]) return;
-    const int cz = (int)(i % dz), cy = (int)((i / dz) % dy), cx = (int)(i / ((size_t)dz * dy));
-    up[((size_t)(cx >> 1) * uy + (cy >> 1)) * uz + (cz >> 1)] = 1;
+    pyr_mark(up, (int)(i / ((size_t)dz * dy)), (int)((i / dz) % dy), (int)(i % dz), uy, uz);
 }
 
 // Search results. Candidates are ordered by (squared distance, index); bound() is the distance beyond which
@@ -146,18 +153,31 @@ __device__ __forceinline__ double box_lb2(double qx, double qy, double qz, doubl
            axis_gap2(qz, oz + k * side, oz + (k + 1) * side, margin);
 }
 
-constexpr int NN_LEVELS = MAXLEV + 1;   // per-thread walk state: one word per pyramid level plus a virtual root
+constexpr int NN_LEVELS = MAXLEV + 1;   // per-thread walk state: one word per pyramid level
+
+// Children of a node in visiting order for a query whose nearest octant is `near`: bit t of the result is
+// child near ^ j(t), with j = 0, 1, 2, 4, 3, 5, 6, 7 (by number of axes in which the child lies on the far
+// side). XOR of the child number is a bit permutation of the mask: swap neighbours, pairs, halves.
+__device__ __forceinline__ unsigned pyr_visit_order(unsigned m, int near) {
+    if (near & 1) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+    if (near & 2) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+    if (near & 4) m = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    const unsigned x = ((m >> 3) ^ (m >> 4)) & 1u;
+    return m ^ (x << 3) ^ (x << 4);
+}
 
 // Exact nearest neighbour. Fast path: the query's own cell and the 26 around it; it is final when the
 // best distance found is smaller than the distance to everything outside that 3x3x3 block. Otherwise
 // (query far from the cloud, or a large empty gap) a depth-first walk down the occupancy pyramid,
-// nearer children first, skipping empty subtrees and those whose box is farther than the best so far.
-// The walk keeps one word per level (the node being expanded and how many of its children are done),
-// in LDS at `state[level * sstride]`; `loff` are the per-level flag offsets staged in LDS.
+// nearer children first, skipping empty subtrees (one mask byte per node tells which children hold points)
+// and those whose box is farther than the best so far. The walk keeps one word per level in LDS at
+// `state[level * sstride]`; `loff` are the per-level mask offsets staged in LDS.
+// `b` comes in initialised: empty (init()), or holding candidates that are real target points, e.g. the
+// correspondence of the previous ICP iteration, whose distance then prunes the search from the start; the
+// result does not depend on them (a candidate met again is not entered twice, equal distances still go to
+// the lower index because cells are only skipped when their bound is strictly larger).
 template <class R>
-__device__ R nn_search_t(const GridView& g, double qx, double qy, double qz, unsigned* state, int sstride, const unsigned* loff) {
-    R b;
-    b.init();
+__device__ R nn_search_t(const GridView& g, double qx, double qy, double qz, unsigned* state, int sstride, const unsigned* loff, R b) {
     const int cx = cell_coord((float)qx, g.minx, g.inv, g.dx), cy = cell_coord((float)qy, g.miny, g.inv, g.dy),
               cz = cell_coord((float)qz, g.minz, g.inv, g.dz);
     const double h = (double)g.h;
@@ -193,46 +213,154 @@ __device__ R nn_search_t(const GridView& g, double qx, double qy, double qz, uns
     if (cz - 2 >= 0)        { const double t = fmax(qz - (oz + (cz - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
     if (outside > b.bound()) return b;
 
-    // Pyramid walk. state[l] = coordinates of the node at level l being expanded (3 x 9 bits) | number
-    // of its children already handled (4 bits, at bit 27). Level nlev is a virtual root over the (at most
-    // 2 x 2 x 2) cells of the top level.
+    // Pyramid walk from the root node (level nlev - 1, a single node). The node being expanded is (l; ni, nj,
+    // nk); `vis` holds its children that hold points and are not handled yet, bit t = the t-th child in
+    // visiting order (the octant the query lies in first, then the three that differ in one axis, ...).
+    // state[l] keeps {vis, near octant} of the ancestor at level l while the walk is below it; coordinates
+    // of an ancestor are those of the node shifted right.
     const int top = g.nlev - 1;
-    if (top == 0) return b;   // a grid of at most 2x2x2 cells was covered by the block above
-    int l = g.nlev;
-    state[l * sstride] = 0;
-    const unsigned order = 0x76534210u;   // children by number of flipped axes: 0,1,2,4,3,5,6,7
-    while (l <= g.nlev) {
-        const unsigned w = state[l * sstride];
-        const int t = (int)(w >> 27);
-        if (t == 8) { l++; continue; }
-        state[l * sstride] = w + (1u << 27);
-        const int ni = (int)((w >> 18) & 511), nj = (int)((w >> 9) & 511), nk = (int)(w & 511);
-        const int cl = l - 1;
-        const double cside = h * (double)(1 << cl);
-        const int near = (qx >= ox + (2 * ni + 1) * cside ? 4 : 0) | (qy >= oy + (2 * nj + 1) * cside ? 2 : 0) |
-                         (qz >= oz + (2 * nk + 1) * cside ? 1 : 0);
-        const int oct = near ^ (int)((order >> (4 * t)) & 7);
+    if (top == 0) return b;   // a single cell was covered by the block above
+    int l = top, ni = 0, nj = 0, nk = 0, near = 0;
+    unsigned vis = 0;
+    bool enter = true;
+    for (;;) {
+        if (enter) {          // (l; ni, nj, nk) has just become the node to expand
+            const int ndy = lev_dim(g.dy, l), ndz = lev_dim(g.dz, l);
+            const unsigned m = g.flags[loff[l] + ((size_t)ni * ndy + nj) * ndz + nk];
+            const double half = h * (double)(1 << (l - 1));
+            near = (qx >= ox + (2 * ni + 1) * half ? 4 : 0) | (qy >= oy + (2 * nj + 1) * half ? 2 : 0) | (qz >= oz + (2 * nk + 1) * half ? 1 : 0);
+            vis = pyr_visit_order(m, near);
+            enter = false;
+        }
+        if (vis == 0) {       // done with this node: back to its parent
+            if (l == top) break;
+            l++; ni >>= 1; nj >>= 1; nk >>= 1;
+            const unsigned w = state[l * sstride];
+            vis = w & 0xffu; near = (int)(w >> 8);
+            continue;
+        }
+        const int t = __ffs((int)vis) - 1;
+        vis &= vis - 1;
+        const int oct = near ^ (t == 3 ? 4 : t == 4 ? 3 : t);
         const int ci = 2 * ni + (oct >> 2), cj = 2 * nj + ((oct >> 1) & 1), ck = 2 * nk + (oct & 1);
-        const int cdx = lev_dim(g.dx, cl), cdy = lev_dim(g.dy, cl), cdz = lev_dim(g.dz, cl);
-        if (ci >= cdx || cj >= cdy || ck >= cdz) continue;
-        const size_t cidx = ((size_t)ci * cdy + cj) * cdz + ck;
+        const int cl = l - 1;
+        if (box_lb2(qx, qy, qz, ox, oy, oz, h * (double)(1 << cl), ci, cj, ck, margin) > b.bound()) continue;
         if (cl == 0) {
-            const int2 r = g.range[cidx];
-            if (r.y <= r.x) continue;
-            if (box_lb2(qx, qy, qz, ox, oy, oz, cside, ci, cj, ck, margin) > b.bound()) continue;
-            scan_cell(g, (int)cidx, qx, qy, qz, b);
+            scan_cell(g, (ci * g.dy + cj) * g.dz + ck, qx, qy, qz, b);
         } else {
-            if (!g.flags[loff[cl] + cidx]) continue;
-            if (box_lb2(qx, qy, qz, ox, oy, oz, cside, ci, cj, ck, margin) > b.bound()) continue;
-            l = cl;
-            state[l * sstride] = ((unsigned)ci << 18) | ((unsigned)cj << 9) | (unsigned)ck;
+            state[l * sstride] = vis | ((unsigned)near << 8);
+            l = cl; ni = ci; nj = cj; nk = ck;
+            enter = true;
         }
     }
     return b;
 }
 
-__device__ Best nn_search(const GridView& g, double qx, double qy, double qz, unsigned* state, int sstride, const unsigned* loff) {
-    return nn_search_t<Best>(g, qx, qy, qz, state, sstride, loff);
+// ---- the same search by eight lanes per query -----------------------------------------------------------
+// One lane per query leaves a long chain of dependent loads (mask, cell range, points, next mask ...) and,
+// for clouds of some ten thousand points, fewer waves than the GPU has SIMDs. Here the eight lanes of an
+// aligned group ("octet") share one query: the 27 cells of the first block are dealt out over the lanes,
+// and in the walk lane c owns child c of the node being expanded, so the eight bounds are computed, and at
+// the lowest level the up to eight cells scanned, side by side. All lanes of an octet hold the same walk
+// state; the result (minimum over the lanes by (distance, index)) is the same as the single-lane search's.
+
+// Minimum by (d2, idx) over the octet; every lane gets it.
+__device__ __forceinline__ Best octet_min(Best b) {
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const double d = __shfl_xor(b.d2, o);
+        const int id = __shfl_xor(b.idx, o);
+        if (d < b.d2 || (d == b.d2 && id < b.idx)) { b.d2 = d; b.idx = id; }
+    }
+    return b;
+}
+
+constexpr int NN_OCTETS = 32;   // octets per 256-thread block
+
+// `state`: NN_LEVELS words per octet at stride `sstride` (LDS); `b`: initial candidate, the same in all lanes.
+__device__ Best nn_search8(const GridView& g, double qx, double qy, double qz, unsigned* state, int sstride, const unsigned* loff, Best b) {
+    const int c = (int)(threadIdx.x & 7);
+    const int cx = cell_coord((float)qx, g.minx, g.inv, g.dx), cy = cell_coord((float)qy, g.miny, g.inv, g.dy),
+              cz = cell_coord((float)qz, g.minz, g.inv, g.dz);
+    const double h = (double)g.h;
+    const double margin = 1e-3 * h + 1e-6 * (fabs(qx) + fabs(qy) + fabs(qz));
+    const double ox = (double)g.minx, oy = (double)g.miny, oz = (double)g.minz;
+    // cells c, c + 8, c + 16, c + 24 of the 3x3x3 block
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int cc = c + 8 * r;
+        const int i = cx + cc / 9 - 1, j = cy + (cc / 3) % 3 - 1, k = cz + cc % 3 - 1;
+        if (cc < 27 && i >= 0 && i < g.dx && j >= 0 && j < g.dy && k >= 0 && k < g.dz &&
+            !(box_lb2(qx, qy, qz, ox, oy, oz, h, i, j, k, margin) > b.bound()))
+            scan_cell(g, (i * g.dy + j) * g.dz + k, qx, qy, qz, b);
+    }
+    b = octet_min(b);
+    double outside = INFINITY;
+    if (cx + 2 <= g.dx - 1) { const double t = fmax(ox + (cx + 2) * h - qx - margin, 0.0); outside = fmin(outside, t * t); }
+    if (cx - 2 >= 0)        { const double t = fmax(qx - (ox + (cx - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
+    if (cy + 2 <= g.dy - 1) { const double t = fmax(oy + (cy + 2) * h - qy - margin, 0.0); outside = fmin(outside, t * t); }
+    if (cy - 2 >= 0)        { const double t = fmax(qy - (oy + (cy - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
+    if (cz + 2 <= g.dz - 1) { const double t = fmax(oz + (cz + 2) * h - qz - margin, 0.0); outside = fmin(outside, t * t); }
+    if (cz - 2 >= 0)        { const double t = fmax(qz - (oz + (cz - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
+    if (outside > b.bound()) return b;
+    const int top = g.nlev - 1;
+    if (top == 0) return b;
+
+    // Walk: (l; ni, nj, nk) is the node being expanded, m its child mask, done the children already entered.
+    // state[l] keeps {m, done} of the ancestor at level l while the walk is below it.
+    int l = top, ni = 0, nj = 0, nk = 0;
+    unsigned m = g.flags[loff[top]], done = 0;
+    for (;;) {
+        const int cl = l - 1;
+        const int ci = 2 * ni + (c >> 2), cj = 2 * nj + ((c >> 1) & 1), ck = 2 * nk + (c & 1);
+        const bool has = ((m & ~done) >> c) & 1u;
+        const double lb = has ? box_lb2(qx, qy, qz, ox, oy, oz, h * (double)(1 << cl), ci, cj, ck, margin) : INFINITY;
+        const bool ok = has && !(lb > b.bound());
+        int into = -1;                       // child to enter, the same in all lanes
+        if (cl == 0) {
+            // the children are cells: every lane scans its own (those of the first block are done already)
+            const bool seen = ci >= cx - 1 && ci <= cx + 1 && cj >= cy - 1 && cj <= cy + 1 && ck >= cz - 1 && ck <= cz + 1;
+            if (ok && !seen) scan_cell(g, (ci * g.dy + cj) * g.dz + ck, qx, qy, qz, b);
+            b = octet_min(b);
+        } else {
+            Best pick;
+            pick.d2 = ok ? lb : INFINITY; pick.idx = c;
+            pick = octet_min(pick);          // the nearest box first
+            if (pick.d2 < INFINITY) into = pick.idx;
+        }
+        if (into >= 0) {
+            done |= 1u << into;
+            state[l * sstride] = m | (done << 8);
+            l = cl; ni = 2 * ni + (into >> 2); nj = 2 * nj + ((into >> 1) & 1); nk = 2 * nk + (into & 1);
+            m = g.flags[loff[l] + ((size_t)ni * lev_dim(g.dy, l) + nj) * lev_dim(g.dz, l) + nk];
+            done = 0;
+        } else {
+            if (l == top) break;
+            l++; ni >>= 1; nj >>= 1; nk >>= 1;
+            const unsigned w = state[l * sstride];
+            m = w & 0xffu; done = w >> 8;
+        }
+    }
+    return b;
+}
+
+__device__ __forceinline__ Best best_empty() { Best b; b.init(); return b; }
+
+// The previous correspondence of a source point as the first candidate: (distance to it now, its index);
+// empty when there is none (index < 0) or it does not belong to the current target.
+__device__ __forceinline__ Best best_seed(const int* __restrict__ seed, size_t i, size_t nt, const float* __restrict__ tgt_xyz, double qx, double qy,
+                                          double qz) {
+    Best b;
+    b.init();
+    if (seed) {
+        const int j = seed[i];
+        if (j >= 0 && (size_t)j < nt) {
+            const double dx = qx - (double)tgt_xyz[3 * (size_t)j], dy = qy - (double)tgt_xyz[3 * (size_t)j + 1], dz = qz - (double)tgt_xyz[3 * (size_t)j + 2];
+            b.d2 = (dx * dx + dy * dy) + dz * dz;
+            b.idx = j;
+        }
+    }
+    return b;
 }
 
 // K nearest target points of every query, ascending by (squared distance, index); slots beyond the number
@@ -246,7 +374,9 @@ __global__ __launch_bounds__(256) void k_knn(GridView g, const double* __restric
     __syncthreads();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const BestK<K> b = nn_search_t<BestK<K>>(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], stk + threadIdx.x, 256, s_loff);
+    BestK<K> b0;
+    b0.init();
+    const BestK<K> b = nn_search_t<BestK<K>>(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], stk + threadIdx.x, 256, s_loff, b0);
 #pragma unroll
     for (int k = 0; k < K; k++) {
         if (k < kout) {
@@ -257,26 +387,28 @@ __global__ __launch_bounds__(256) void k_knn(GridView g, const double* __restric
 }
 
 __global__ __launch_bounds__(256) void k_nn(GridView g, const double* __restrict__ q, size_t n, int* __restrict__ idx, double* __restrict__ d2) {
-    __shared__ unsigned stk[NN_LEVELS * 256];
+    __shared__ unsigned stk[NN_LEVELS * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;   // eight lanes per query
     if (i >= n) return;
-    const Best b = nn_search(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], stk + threadIdx.x, 256, s_loff);
-    if (idx) idx[i] = b.idx;
-    if (d2) d2[i] = b.d2;
+    const Best b = nn_search8(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], stk + (threadIdx.x >> 3), NN_OCTETS, s_loff, best_empty());
+    if ((threadIdx.x & 7) == 0) {
+        if (idx) idx[i] = b.idx;
+        if (d2) d2[i] = b.d2;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_nn_distance(GridView g, const float* __restrict__ q, size_t n, float* __restrict__ out) {
-    __shared__ unsigned stk[NN_LEVELS * 256];
+    __shared__ unsigned stk[NN_LEVELS * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     if (i >= n) return;
-    const Best b = nn_search(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2], stk + threadIdx.x, 256, s_loff);
-    out[i] = (float)__dsqrt_rn(b.d2);
+    const Best b = nn_search8(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2], stk + (threadIdx.x >> 3), NN_OCTETS, s_loff, best_empty());
+    if ((threadIdx.x & 7) == 0) out[i] = (float)__dsqrt_rn(b.d2);
 }
 
 struct Mat34 { double m[12]; };
@@ -284,16 +416,17 @@ struct Mat34 { double m[12]; };
 // One ICP pass: p = T * [src;1] (multiply then add, k = 0..3 from a zero accumulator), nearest target
 // point q, and block-partial sums {p, q, p q^T, |p-q|^2}.
 __global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __restrict__ src, size_t n, Mat34 T,
-                                                  const float* __restrict__ tgt_xyz, double* __restrict__ partials,
-                                                  int* __restrict__ idx_out) {
-    __shared__ unsigned stk[NN_LEVELS * 256];
+                                                  const float* __restrict__ tgt_xyz, size_t nt, double* __restrict__ partials,
+                                                  int* __restrict__ idx_out, int* __restrict__ seed) {
+    __shared__ unsigned stk[NN_LEVELS * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
     double acc[ICPX_NSUMS];
 #pragma unroll
     for (int k = 0; k < ICPX_NSUMS; k++) acc[k] = 0.0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const bool first = (threadIdx.x & 7) == 0;   // eight lanes per source point; the first one keeps the sums
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n; i += ((size_t)gridDim.x * blockDim.x) >> 3) {
         const float4 s = src[i];
         double p[3];
 #pragma unroll
@@ -305,7 +438,9 @@ __global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __re
             a += T.m[4 * r + 3];
             p[r] = a;
         }
-        const Best b = nn_search(g, p[0], p[1], p[2], stk + threadIdx.x, 256, s_loff);
+        const Best b = nn_search8(g, p[0], p[1], p[2], stk + (threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(seed, i, nt, tgt_xyz, p[0], p[1], p[2]));
+        if (!first) continue;
+        if (seed) seed[i] = b.idx == 0x7fffffff ? -1 : b.idx;
         if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
         // a NaN in T leaves no candidate: read point 0 then (the sums are NaN anyway) instead of an invalid index
         const size_t j = b.idx == 0x7fffffff ? 0 : (size_t)b.idx;
@@ -335,12 +470,13 @@ __global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __re
 // order like the value), o itself as the sort value, p and the correspondence.
 __global__ __launch_bounds__(256) void k_icp_pairs(GridView g, const float4* __restrict__ src, size_t n, Mat34 T,
                                                    unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
-                                                   double* __restrict__ pbuf, int* __restrict__ idx) {
-    __shared__ unsigned stk[NN_LEVELS * 256];
+                                                   double* __restrict__ pbuf, int* __restrict__ idx, const float* __restrict__ tgt_xyz, size_t nt,
+                                                   int* __restrict__ seed) {
+    __shared__ unsigned stk[NN_LEVELS * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;   // eight lanes per source point
     if (i >= n) return;
     const float4 s = src[i];
     double p[3];
@@ -353,7 +489,9 @@ __global__ __launch_bounds__(256) void k_icp_pairs(GridView g, const float4* __r
         a += T.m[4 * r + 3];
         p[r] = a;
     }
-    const Best b = nn_search(g, p[0], p[1], p[2], stk + threadIdx.x, 256, s_loff);
+    const Best b = nn_search8(g, p[0], p[1], p[2], stk + (threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(seed, i, nt, tgt_xyz, p[0], p[1], p[2]));
+    if ((threadIdx.x & 7) != 0) return;
+    if (seed) seed[i] = b.idx == 0x7fffffff ? -1 : b.idx;
     const size_t o = (size_t)__float_as_int(s.w);
     keys[o] = (unsigned long long)__double_as_longlong(b.d2);
     vals[o] = (unsigned)o;
@@ -483,30 +621,29 @@ int icpx_grid_build(icpx_ctx* ctx) {
         int nlev = 1;
         unsigned off = 0;
         ctx->pyr_dim[0][0] = d[0]; ctx->pyr_dim[0][1] = d[1]; ctx->pyr_dim[0][2] = d[2]; ctx->pyr_off[0] = 0;
-        while ((d[0] > 2 || d[1] > 2 || d[2] > 2) && nlev < MAXLEV) {
+        while ((d[0] > 1 || d[1] > 1 || d[2] > 1) && nlev < MAXLEV) {   // dims <= 1024: ten halvings reach the root
             for (int c = 0; c < 3; c++) d[c] = (d[c] + 1) / 2;
             ctx->pyr_dim[nlev][0] = d[0]; ctx->pyr_dim[nlev][1] = d[1]; ctx->pyr_dim[nlev][2] = d[2];
             ctx->pyr_off[nlev] = off;
-            off += (unsigned)d[0] * d[1] * d[2];
+            off += ((unsigned)d[0] * d[1] * d[2] + 3u) & ~3u;            // levels start on a word (the mask bits are set with word atomics)
             nlev++;
         }
         for (int l = nlev; l < MAXLEV; l++) { ctx->pyr_dim[l][0] = ctx->pyr_dim[l][1] = ctx->pyr_dim[l][2] = 0; ctx->pyr_off[l] = 0; }
         ctx->pyr_nlev = nlev;
         ICPX_TRY(icpx_reserve(ctx, ctx->pyr_tab, MAXLEV * sizeof(unsigned)));
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->pyr_tab.p, ctx->pyr_off, MAXLEV * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-        ICPX_TRY(icpx_reserve(ctx, ctx->pyr_flags, off ? off : 1));
-        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->pyr_flags.p, 0, off ? off : 1, ctx->stream));
+        ICPX_TRY(icpx_reserve(ctx, ctx->pyr_flags, off ? off : 4));
+        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->pyr_flags.p, 0, off ? off : 4, ctx->stream));
         unsigned char* fl = ctx->pyr_flags.as<unsigned char>();
         for (int l = 1; l < nlev; l++) {
             const int* lo = ctx->pyr_dim[l - 1]; const int* up = ctx->pyr_dim[l];
             const size_t cells = (size_t)lo[0] * lo[1] * lo[2];
             const unsigned nb = (unsigned)((cells + 255) / 256);
+            unsigned* upw = reinterpret_cast<unsigned*>(fl + ctx->pyr_off[l]);
             if (l == 1)
-                hipLaunchKernelGGL(k_pyr_from_cells, dim3(nb), dim3(256), 0, ctx->stream, ctx->cell_range.as<int2>(), lo[0], lo[1], lo[2],
-                                   fl + ctx->pyr_off[1], up[0], up[1], up[2]);
+                hipLaunchKernelGGL(k_pyr_from_cells, dim3(nb), dim3(256), 0, ctx->stream, ctx->cell_range.as<int2>(), lo[0], lo[1], lo[2], upw, up[1], up[2]);
             else
-                hipLaunchKernelGGL(k_pyr_from_flags, dim3(nb), dim3(256), 0, ctx->stream, fl + ctx->pyr_off[l - 1], lo[0], lo[1], lo[2],
-                                   fl + ctx->pyr_off[l], up[0], up[1], up[2]);
+                hipLaunchKernelGGL(k_pyr_from_masks, dim3(nb), dim3(256), 0, ctx->stream, fl + ctx->pyr_off[l - 1], lo[0], lo[1], lo[2], upw, up[1], up[2]);
         }
         ICPX_TRY(icpx_launch_check(ctx, "pyramid kernels"));
     }
@@ -528,7 +665,7 @@ extern "C" int icpx_nn(icpx_ctx* ctx, const double* q_xyz, size_t n, int where, 
         if (idx) { ICPX_TRY(icpx_reserve(ctx, ctx->scratch_idx, n * sizeof(int))); didx = ctx->scratch_idx.as<int>(); }
         if (d2) { ICPX_TRY(icpx_reserve(ctx, ctx->scratch_d2, n * sizeof(double))); dd2 = ctx->scratch_d2.as<double>(); }
     }
-    hipLaunchKernelGGL(k_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, view_of(ctx), dq, n, didx, dd2);
+    hipLaunchKernelGGL(k_nn, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, ctx->stream, view_of(ctx), dq, n, didx, dd2);
     ICPX_TRY(icpx_launch_check(ctx, "k_nn"));
     if (where == ICPX_HOST) {
         if (idx) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(idx, didx, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -581,7 +718,7 @@ extern "C" int icpx_nn_distance(icpx_ctx* ctx, const float* q_xyz, size_t n, int
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, q_xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         dq = ctx->scratch_q.as<float>(); dout = ctx->scratch_d2.as<float>();
     }
-    hipLaunchKernelGGL(k_nn_distance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, view_of(ctx), dq, n, dout);
+    hipLaunchKernelGGL(k_nn_distance, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, ctx->stream, view_of(ctx), dq, n, dout);
     ICPX_TRY(icpx_launch_check(ctx, "k_nn_distance"));
     if (where == ICPX_HOST) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(dist, dout, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -598,6 +735,9 @@ extern "C" int icpx_set_source(icpx_ctx* ctx, const float* xyz, size_t n, size_t
     ICPX_TRY(icpx_reserve(ctx, ctx->src_pts, n * sizeof(float4)));
     ICPX_TRY(icpx_stage_points4(ctx, xyz, n, stride_bytes, where, ctx->src_pts.as<float4>()));
     ICPX_TRY(icpx_morton_sort4(ctx, ctx->src_pts.as<float4>(), n));
+    // correspondences of the last pass, by sorted position (-1 = none): the next pass starts its search from them
+    ICPX_TRY(icpx_reserve(ctx, ctx->nn_seed, n * sizeof(int)));
+    ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->nn_seed.p, 0xff, n * sizeof(int), ctx->stream));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->ns = n;
     return ICPX_OK;
@@ -607,12 +747,12 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     if (!ctx->grid_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_step: no target cloud (call icpx_set_target first)");
     if (ctx->ns == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_step: no source cloud (call icpx_set_source first)");
     if (!T) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_step: T is NULL");
-    const int blocks = (int)std::min<size_t>((ctx->ns + 255) / 256, (size_t)ctx->num_cus * 32);
+    const int blocks = (int)std::min<size_t>((ctx->ns + 31) / 32, (size_t)ctx->num_cus * 32);   // 32 source points per block
     ICPX_TRY(icpx_reserve(ctx, ctx->partials, (size_t)blocks * ICPX_NSUMS * sizeof(double)));
     Mat34 M;
     for (int k = 0; k < 12; k++) M.m[k] = T[k];
     hipLaunchKernelGGL(k_icp_step, dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), ctx->src_pts.as<float4>(), ctx->ns, M,
-                       ctx->tgt_xyz.as<float>(), ctx->partials.as<double>(), idx_dev);
+                       ctx->tgt_xyz.as<float>(), ctx->nt, ctx->partials.as<double>(), idx_dev, ctx->nn_seed.as<int>());
     hipLaunchKernelGGL(k_reduce_sums, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, sums_dev);
     return icpx_launch_check(ctx, "k_icp_step");
 }
@@ -655,9 +795,9 @@ extern "C" int icpx_icp_step_trimmed(icpx_ctx* ctx, const double T[16], uint64_t
     ICPX_TRY(icpx_reserve(ctx, ctx->partials, (size_t)blocks * ICPX_NSUMS * sizeof(double)));
     Mat34 M;
     for (int k = 0; k < 12; k++) M.m[k] = T[k];
-    hipLaunchKernelGGL(k_icp_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, view_of(ctx), ctx->src_pts.as<float4>(), n, M,
+    hipLaunchKernelGGL(k_icp_pairs, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, ctx->stream, view_of(ctx), ctx->src_pts.as<float4>(), n, M,
                        ctx->trim_keys_a.as<unsigned long long>(), ctx->trim_vals_a.as<unsigned>(), ctx->trim_p.as<double>(),
-                       ctx->trim_idx.as<int>());
+                       ctx->trim_idx.as<int>(), ctx->tgt_xyz.as<float>(), ctx->nt, ctx->nn_seed.as<int>());
     ICPX_TRY(icpx_launch_check(ctx, "k_icp_pairs"));
     ICPX_TRY(icpx_sort_pairs64(ctx, n, ctx->trim_keys_a.as<unsigned long long>(), ctx->trim_keys_b.as<unsigned long long>(),
                                ctx->trim_vals_a.as<unsigned>(), ctx->trim_vals_b.as<unsigned>()));

@@ -1,10 +1,11 @@
 """Wall time of the reference's config 1 (bunny000 -> bunny045, 30 iterations) through the host class (GPU)."""
-import sys, time
+import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from icp_amd.host import SingleThreadIcp
-src = np.fromfile("tests/golden/bunny000.xyz.f32", np.float32).reshape(-1, 3)
-tgt = np.fromfile("tests/golden/bunny045.xyz.f32", np.float32).reshape(-1, 3)
+src = np.fromfile(os.path.join(ROOT, "tests/golden/bunny000.xyz.f32"), np.float32).reshape(-1, 3)
+tgt = np.fromfile(os.path.join(ROOT, "tests/golden/bunny045.xyz.f32"), np.float32).reshape(-1, 3)
 icp = SingleThreadIcp(src, tgt, iters=30)
 icp.registration()
 for _ in range(3):
