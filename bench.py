@@ -207,6 +207,18 @@ def main():
         extra["nn_roofline_frac"] = (36.0 * n + 12.0 * n * world) * iters / el / 1e9 / (HBM_PEAK_GBS * world)
         ctx2.close()
 
+        # configs[0], the reference's own run: bunny000 -> bunny045, 30 iterations through the host class
+        # (src/main.cpp:270-284); every rank runs the whole registration
+        from icp_amd.host import SingleThreadIcp
+        st = SingleThreadIcp(load_scan("bunny000"), load_scan("bunny045"), iters=30, device=local)
+        st.registration()
+        barrier(); t0 = time.perf_counter()
+        for _ in range(5):
+            st.registration()
+        barrier()
+        extra["icp_bunny045_30it_ms"] = max_over_ranks(time.perf_counter() - t0) / 5 * 1e3
+        del st
+
         # Go-ICP on the reference's bunny pair (model bunny000 = bun315/bun000, data bun315/bun270), both
         # clouds normalised isotropically into [-1,1]^3, DT 300^3, mse 1e-3; every bound batch is split
         # over the ranks and combined by one sum all-reduce.
@@ -250,6 +262,10 @@ def main():
         el = time.perf_counter() - t0
         cpu = {"value": voxels * reps / el, "unit": "voxels/s", "cores": threads, "kind": "port",
                "sample": f"{reps} builds of the same 300^3 bunny045 grid (three-pass EDT restatement, OpenMP)"}
+        if not args.no_extra:   # the CPU restatement of configs[0] (kd-tree search, queries spread over the same threads)
+            t0 = time.perf_counter()
+            O.icp(load_scan("bunny000"), tgt, 30, threads=threads)
+            cpu["icp_bunny045_30it_ms"] = (time.perf_counter() - t0) * 1e3
 
     if rank == 0:
         line = {"metric": "EDT voxels/s", "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
