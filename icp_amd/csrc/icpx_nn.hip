@@ -276,9 +276,11 @@ __device__ __forceinline__ Best octet_min(Best b) {
 }
 
 constexpr int NN_OCTETS = 32;   // octets per 256-thread block
+constexpr int NN_STACK = 72;    // 1 + 7 entries for each of the (at most ten) levels above the cells, rounded up
 
-// `state`: NN_LEVELS words per octet at stride `sstride` (LDS); `b`: initial candidate, the same in all lanes.
-__device__ Best nn_search8(const GridView& g, double qx, double qy, double qz, unsigned* state, int sstride, const unsigned* loff, Best b) {
+// `snode`, `slb`: the walk's stack in LDS, NN_STACK entries per octet, entry k of octet o at [k * NN_OCTETS + o];
+// `b`: initial candidate, the same in all lanes.
+__device__ Best nn_search8(const GridView& g, double qx, double qy, double qz, unsigned* snode, double* slb, const unsigned* loff, Best b) {
     const int c = (int)(threadIdx.x & 7);
     const int cx = cell_coord((float)qx, g.minx, g.inv, g.dx), cy = cell_coord((float)qy, g.miny, g.inv, g.dy),
               cz = cell_coord((float)qz, g.minz, g.inv, g.dz);
@@ -306,40 +308,47 @@ __device__ Best nn_search8(const GridView& g, double qx, double qy, double qz, u
     const int top = g.nlev - 1;
     if (top == 0) return b;
 
-    // Walk: (l; ni, nj, nk) is the node being expanded, m its child mask, done the children already entered.
-    // state[l] keeps {m, done} of the ancestor at level l while the walk is below it.
-    int l = top, ni = 0, nj = 0, nk = 0;
-    unsigned m = g.flags[loff[top]], done = 0;
-    for (;;) {
+    // Walk: a stack of nodes still to expand, each with the bound of its box; the node on top is the nearest
+    // of those pushed last. Expanding a node: lane c bounds child c; at level 1 the children are cells and
+    // every lane scans its own, above that the children that can still hold a nearer point are pushed, the
+    // farthest first (in the order of visit_order: the octant of the query, then one axis flipped, ...).
+    // A node whose bound has been overtaken by the best distance since it was pushed is dropped when popped.
+    // Depth: one pop and at most eight pushes per level, NN_STACK covers the ten levels above the cells.
+    const int oc = (int)(threadIdx.x >> 3);
+    int sp = 1;
+    snode[oc] = (unsigned)top << 27;
+    slb[oc] = 0.0;
+    while (sp > 0) {
+        sp--;
+        const unsigned node = snode[sp * NN_OCTETS + oc];
+        if (slb[sp * NN_OCTETS + oc] > b.bound()) continue;
+        const int l = (int)(node >> 27), ni = (int)((node >> 18) & 511), nj = (int)((node >> 9) & 511), nk = (int)(node & 511);
+        const unsigned m = g.flags[loff[l] + ((size_t)ni * lev_dim(g.dy, l) + nj) * lev_dim(g.dz, l) + nk];
         const int cl = l - 1;
+        const double cside = h * (double)(1 << cl);
         const int ci = 2 * ni + (c >> 2), cj = 2 * nj + ((c >> 1) & 1), ck = 2 * nk + (c & 1);
-        const bool has = ((m & ~done) >> c) & 1u;
-        const double lb = has ? box_lb2(qx, qy, qz, ox, oy, oz, h * (double)(1 << cl), ci, cj, ck, margin) : INFINITY;
+        const bool has = (m >> c) & 1u;
+        const double lb = has ? box_lb2(qx, qy, qz, ox, oy, oz, cside, ci, cj, ck, margin) : INFINITY;
         const bool ok = has && !(lb > b.bound());
-        int into = -1;                       // child to enter, the same in all lanes
         if (cl == 0) {
             // the children are cells: every lane scans its own (those of the first block are done already)
             const bool seen = ci >= cx - 1 && ci <= cx + 1 && cj >= cy - 1 && cj <= cy + 1 && ck >= cz - 1 && ck <= cz + 1;
             if (ok && !seen) scan_cell(g, (ci * g.dy + cj) * g.dz + ck, qx, qy, qz, b);
             b = octet_min(b);
-        } else {
-            Best pick;
-            pick.d2 = ok ? lb : INFINITY; pick.idx = c;
-            pick = octet_min(pick);          // the nearest box first
-            if (pick.d2 < INFINITY) into = pick.idx;
+            continue;
         }
-        if (into >= 0) {
-            done |= 1u << into;
-            state[l * sstride] = m | (done << 8);
-            l = cl; ni = 2 * ni + (into >> 2); nj = 2 * nj + ((into >> 1) & 1); nk = 2 * nk + (into & 1);
-            m = g.flags[loff[l] + ((size_t)ni * lev_dim(g.dy, l) + nj) * lev_dim(g.dz, l) + nk];
-            done = 0;
-        } else {
-            if (l == top) break;
-            l++; ni >>= 1; nj >>= 1; nk >>= 1;
-            const unsigned w = state[l * sstride];
-            m = w & 0xffu; done = w >> 8;
+        const unsigned cand = (unsigned)(__ballot(ok) >> (threadIdx.x & 56)) & 0xffu;
+        if (cand == 0) continue;
+        const int near = (qx >= ox + (2 * ni + 1) * cside ? 4 : 0) | (qy >= oy + (2 * nj + 1) * cside ? 2 : 0) | (qz >= oz + (2 * nk + 1) * cside ? 1 : 0);
+        const unsigned vis = pyr_visit_order(cand, near);
+        const int jc = c ^ near, t = jc == 3 ? 4 : jc == 4 ? 3 : jc;          // this lane's place in the visiting order
+        const int n = __popc(cand);
+        if (ok) {
+            const int at = sp + n - 1 - __popc(vis & ((1u << t) - 1u));
+            snode[at * NN_OCTETS + oc] = ((unsigned)cl << 27) | ((unsigned)ci << 18) | ((unsigned)cj << 9) | (unsigned)ck;
+            slb[at * NN_OCTETS + oc] = lb;
         }
+        sp += n;
     }
     return b;
 }
@@ -387,13 +396,14 @@ __global__ __launch_bounds__(256) void k_knn(GridView g, const double* __restric
 }
 
 __global__ __launch_bounds__(256) void k_nn(GridView g, const double* __restrict__ q, size_t n, int* __restrict__ idx, double* __restrict__ d2) {
-    __shared__ unsigned stk[NN_LEVELS * NN_OCTETS];
+    __shared__ unsigned snode[NN_STACK * NN_OCTETS];
+    __shared__ double slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;   // eight lanes per query
     if (i >= n) return;
-    const Best b = nn_search8(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], stk + (threadIdx.x >> 3), NN_OCTETS, s_loff, best_empty());
+    const Best b = nn_search8(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], snode, slb, s_loff, best_empty());
     if ((threadIdx.x & 7) == 0) {
         if (idx) idx[i] = b.idx;
         if (d2) d2[i] = b.d2;
@@ -401,13 +411,14 @@ __global__ __launch_bounds__(256) void k_nn(GridView g, const double* __restrict
 }
 
 __global__ __launch_bounds__(256) void k_nn_distance(GridView g, const float* __restrict__ q, size_t n, float* __restrict__ out) {
-    __shared__ unsigned stk[NN_LEVELS * NN_OCTETS];
+    __shared__ unsigned snode[NN_STACK * NN_OCTETS];
+    __shared__ double slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     if (i >= n) return;
-    const Best b = nn_search8(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2], stk + (threadIdx.x >> 3), NN_OCTETS, s_loff, best_empty());
+    const Best b = nn_search8(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2], snode, slb, s_loff, best_empty());
     if ((threadIdx.x & 7) == 0) out[i] = (float)__dsqrt_rn(b.d2);
 }
 
@@ -418,7 +429,8 @@ struct Mat34 { double m[12]; };
 __global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __restrict__ src, size_t n, Mat34 T,
                                                   const float* __restrict__ tgt_xyz, size_t nt, double* __restrict__ partials,
                                                   int* __restrict__ idx_out, int* __restrict__ seed) {
-    __shared__ unsigned stk[NN_LEVELS * NN_OCTETS];
+    __shared__ unsigned snode[NN_STACK * NN_OCTETS];
+    __shared__ double slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
@@ -438,7 +450,7 @@ __global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __re
             a += T.m[4 * r + 3];
             p[r] = a;
         }
-        const Best b = nn_search8(g, p[0], p[1], p[2], stk + (threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(seed, i, nt, tgt_xyz, p[0], p[1], p[2]));
+        const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, s_loff, best_seed(seed, i, nt, tgt_xyz, p[0], p[1], p[2]));
         if (!first) continue;
         if (seed) seed[i] = b.idx == 0x7fffffff ? -1 : b.idx;
         if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
@@ -472,7 +484,8 @@ __global__ __launch_bounds__(256) void k_icp_pairs(GridView g, const float4* __r
                                                    unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
                                                    double* __restrict__ pbuf, int* __restrict__ idx, const float* __restrict__ tgt_xyz, size_t nt,
                                                    int* __restrict__ seed) {
-    __shared__ unsigned stk[NN_LEVELS * NN_OCTETS];
+    __shared__ unsigned snode[NN_STACK * NN_OCTETS];
+    __shared__ double slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(256) void k_icp_pairs(GridView g, const float4* __r
         a += T.m[4 * r + 3];
         p[r] = a;
     }
-    const Best b = nn_search8(g, p[0], p[1], p[2], stk + (threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(seed, i, nt, tgt_xyz, p[0], p[1], p[2]));
+    const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, s_loff, best_seed(seed, i, nt, tgt_xyz, p[0], p[1], p[2]));
     if ((threadIdx.x & 7) != 0) return;
     if (seed) seed[i] = b.idx == 0x7fffffff ? -1 : b.idx;
     const size_t o = (size_t)__float_as_int(s.w);
