@@ -595,6 +595,9 @@ int icpx_grid_build(icpx_ctx* ctx) {
     ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, ctx->sorted_pts.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     for (int attempt = 0; attempt < 2; attempt++) {
         int dim[3];
+        // No axis may need more than 1024 cells: coordinates beyond the last cell would be filed under it
+        // while lying outside its box, and the search's bounds rely on the boxes.
+        h = std::max(h, emax / 1023.0);
         for (;;) {
             double cells = 1.0;
             for (int c = 0; c < 3; c++) { dim[c] = (int)std::min(1024.0, std::floor(ext[c] / h) + 1.0); cells *= dim[c]; }

@@ -68,6 +68,30 @@ def test_nn_synthetic_200k(gpu_ctx, oracle):
     assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
 
 
+def test_nn_million_points_and_thin_clouds(gpu_ctx, oracle):
+    """Deep pyramids: a million-point surface (254^3 cells, nine levels) and clouds so thin that one grid
+    dimension reaches the 1024-cell limit while the others are a single cell; queries on, near and far from the
+    cloud, checked against brute force."""
+    rng = np.random.default_rng(17)
+    tgt = synth_surface(1_000_000, 5)
+    near = synth_surface(1500, 6, noise=2e-3).astype(np.float64)
+    far = rng.uniform(-3, 3, (1500, 3))
+    q = np.ascontiguousarray(np.concatenate([tgt[::997].astype(np.float64), near, far]))
+    gpu_ctx.set_target(tgt)
+    idx, d2 = gpu_ctx.nn(q)
+    ridx, rd2 = oracle.nn_brute(q, tgt)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    # 100 000 points on a line, and on a line with a little jitter across it
+    x = rng.uniform(0, 1, 100_000).astype(np.float32)
+    for tgt in (np.c_[x, np.zeros_like(x), np.zeros_like(x)], np.c_[x, 1e-4 * rng.standard_normal(x.size), np.zeros_like(x)]):
+        tgt = np.ascontiguousarray(tgt, np.float32)
+        q = np.ascontiguousarray(np.concatenate([tgt[::50].astype(np.float64), rng.uniform(-0.5, 1.5, (2000, 3)) * [1, 0.2, 0.2]]))
+        gpu_ctx.set_target(tgt)
+        idx, d2 = gpu_ctx.nn(q)
+        ridx, rd2 = oracle.nn_brute(q, tgt)
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
 def test_nn_distance_matches_kdtree_distance(gpu_ctx, oracle, bunny000, bunny045):
     gpu_ctx.set_target(bunny045)
     got = gpu_ctx.nn_distance(bunny000)
