@@ -75,18 +75,13 @@ struct RowRec {
 
 // One workgroup per plane x, one wave per 64 rows y. A lane reads the occupancy words of its row into
 // registers and zeroes them in memory, which leaves the bit array clear for the next build (nothing after
-// the census reads it). The workgroup that finishes last (ticket in counters[6]) also writes the ascending
-// list of the non-empty planes as int32, padded with copies of the last entry up to `padded` entries so
-// that pass x can prefetch whole groups without bounds checks, and zeroes the counter set of the next
-// build.
+// the census reads it).
 constexpr int EDT_MAXW = (ICPX_MAX_DIV + 63) / 64;
 
 __global__ __launch_bounds__(1024) void k_edt_census(u64* __restrict__ bits, int div, int W, RowRec* __restrict__ recs,
-                                                     int* __restrict__ rowcnt, u64* __restrict__ counters, u64* __restrict__ next_counters,
-                                                     int padded, int* __restrict__ planelist) {
+                                                     int* __restrict__ rowcnt, u64* __restrict__ counters) {
     __shared__ int wave_cnt[16];
     __shared__ unsigned wave_occ[16];
-    __shared__ bool is_last;
     const int x = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int y = wv * 64 + lane;
     u64* row = bits + ((size_t)x * div + (y < div ? y : 0)) * W;
@@ -134,17 +129,19 @@ __global__ __launch_bounds__(1024) void k_edt_census(u64* __restrict__ bits, int
     if (threadIdx.x == 0) {
         rowcnt[x] = cnt;
         if (occ_all) atomicAdd(&counters[0], (u64)occ_all);
-        __threadfence();
-        is_last = atomicAdd(&counters[6], 1ull) == (u64)(gridDim.x - 1);
     }
-    __syncthreads();
-    if (!is_last || wv != 0) return;
-    __threadfence();
-    const volatile int* rc = rowcnt;
+}
+
+// The ascending list of the non-empty planes as int32, padded with copies of the last entry up to `padded`
+// entries so that pass x can prefetch whole groups without bounds checks; also zeroes the counter set of the
+// next build. One wave; run by an extra workgroup of pass zy (the census is complete by then and pass x,
+// the only reader, starts after it).
+__device__ void edt_list_planes(const int* __restrict__ rowcnt, int div, int padded, int* __restrict__ planelist, u64* __restrict__ counters,
+                                u64* __restrict__ next_counters, int lane) {
     int np = 0, last = 0;
     for (int base = 0; base < div; base += 64) {
         const int px = base + lane;
-        const bool pany = px < div && rc[px] > 0;
+        const bool pany = px < div && rowcnt[px] > 0;
         const u64 pm = __ballot(pany);
         if (pany) planelist[np + __popcll(pm & ((1ull << lane) - 1))] = px;
         if (pm) last = base + 63 - __clzll(pm);
@@ -476,8 +473,13 @@ __device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int cap, int nc
 template <int G, bool POOL>
 __global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict__ recs, const int* __restrict__ rowcnt,
                                                         int* __restrict__ plane, uint2* __restrict__ spill_buf, u64* __restrict__ counters,
-                                                        int div, int W, int cap, int nch) {
+                                                        int div, int W, int cap, int nch, u64* __restrict__ next_counters, int padded,
+                                                        int* __restrict__ planelist) {
     extern __shared__ unsigned lds[];
+    if (blockIdx.x == (unsigned)(div * W)) {   // the extra workgroup: the plane list for pass x
+        if (threadIdx.x < 64) edt_list_planes(rowcnt, div, padded, planelist, counters, next_counters, (int)threadIdx.x);
+        return;
+    }
     const int x = blockIdx.x / W, c = blockIdx.x % W;
     const int cnt = rowcnt[x];
     if (cnt == 0) return;   // plane without voxels: never read by pass x
@@ -592,7 +594,7 @@ __global__ void k_edt_lookup_round(const int* __restrict__ sq, int div, double m
 }  // namespace
 
 // Two sets of uint64 x 8 behind the occupancy bits, used by alternate builds: {occupied voxels, dropped
-// points, non-empty planes, deepest stack of pass zy, overflow pass zy, overflow pass x, census ticket,
+// points, non-empty planes, deepest stack of pass zy, overflow pass zy, overflow pass x, unused,
 // deepest stack of pass x}
 static u64* edt_counter_set(const icpx_ctx* ctx, int set) {
     return ctx->edt_bits.as<u64>() + (size_t)ctx->div * ctx->div * ctx->edt_words + 8 * (set & 1);
@@ -656,15 +658,15 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
         edt_launch(k_edt_splat, dim3((unsigned)((ctx->nt + 255) / 256)), dim3(256), 0, s, ev, 0, (const float*)ctx->tgt_xyz.as<float>(), ctx->nt,
                    ctx->edt_min[0], ctx->edt_min[1], ctx->edt_min[2], ctx->edt_cell, div, W, ctx->edt_bits.as<u64>(), counters);
     edt_launch(k_edt_census, dim3(div), dim3(64 * nchunk), 0, s, ev, 1, ctx->edt_bits.as<u64>(), div, W, ctx->edt_rowlist.as<RowRec>(),
-               ctx->edt_rowcnt.as<int>(), counters, edt_counter_set(ctx, ctx->edt_epoch ^ 1), (div + 15) / 16 * 16 + 16,
-               ctx->edt_planelist.as<int>());
+               ctx->edt_rowcnt.as<int>(), counters);
     {
         const int G = ctx->edt_zy.groups, cap = ctx->edt_zy.cap, nch = ctx->edt_zy.chunks;
         const bool pool = nch > 0 || ctx->edt_overflowed;
         auto zy = pool ? (G == 1 ? k_edt_pass_zy<1, true> : G == 2 ? k_edt_pass_zy<2, true> : G == 3 ? k_edt_pass_zy<3, true> : k_edt_pass_zy<4, true>)
                        : (G == 1 ? k_edt_pass_zy<1, false> : G == 2 ? k_edt_pass_zy<2, false> : G == 3 ? k_edt_pass_zy<3, false> : k_edt_pass_zy<4, false>);
-        edt_launch(zy, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ev, 2, (const RowRec*)ctx->edt_rowlist.as<RowRec>(),
-                   (const int*)ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, counters, div, W, cap, nch);
+        edt_launch(zy, dim3(div * nchunk + 1), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ev, 2, (const RowRec*)ctx->edt_rowlist.as<RowRec>(),
+                   (const int*)ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, counters, div, W, cap, nch,
+                   edt_counter_set(ctx, ctx->edt_epoch ^ 1), (div + 15) / 16 * 16 + 16, ctx->edt_planelist.as<int>());
     }
     {
         const int G = ctx->edt_x.groups, cap = ctx->edt_x.cap, nch = ctx->edt_x.chunks;
