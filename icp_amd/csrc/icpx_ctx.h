@@ -132,4 +132,4 @@ int icpx_morton_sort4(icpx_ctx* ctx, float4* pts, size_t n);
 // icpx_nn.hip
 int icpx_grid_build(icpx_ctx* ctx);
 // icpx_edt.hip
-int icpx_edt_run(icpx_ctx* ctx);
+int icpx_edt_run(icpx_ctx* ctx, bool report);

@@ -306,12 +306,12 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
 }
 
 // Ends the scan of group g: publishes depth and chunk table (a group without sites gets one entry that
-// loses against every real one) and reports the deepest level count any stack of the wave reached, which
-// the host uses to size the private levels of later builds.
+// loses against every real one) and, when max_depth is not NULL, reports the deepest level count any stack
+// of the wave reached, which the host uses to size the private levels of later builds.
 template <int G, bool POOL>
 __device__ __forceinline__ void env_finish(const Env<G, POOL>& E, int g, EnvTop& e, int deepest, u64* max_depth) {
     for (int o = 32; o; o >>= 1) deepest = max(deepest, __shfl_xor(deepest, o));
-    if (E.lane == 0 && (u64)deepest > *(volatile u64*)max_depth) atomicMax(max_depth, (u64)deepest);
+    if (max_depth && E.lane == 0 && (u64)deepest > *(volatile u64*)max_depth) atomicMax(max_depth, (u64)deepest);
     if (e.q < 0) { e.q = 0; E.store(g, e.wb, e.tb, e.tab, 0, ENV_VMASK, 0); }
     E.depth(g) = (unsigned short)e.q;
     E.table(g) = e.tab;
@@ -474,7 +474,7 @@ template <int G, bool POOL>
 __global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict__ recs, const int* __restrict__ rowcnt,
                                                         int* __restrict__ plane, uint2* __restrict__ spill_buf, u64* __restrict__ counters,
                                                         int div, int W, int cap, int nch, u64* __restrict__ next_counters, int padded,
-                                                        int* __restrict__ planelist) {
+                                                        int* __restrict__ planelist, int report) {
     extern __shared__ unsigned lds[];
     if (blockIdx.x == (unsigned)(div * W)) {   // the extra workgroup: the plane list for pass x
         if (threadIdx.x < 64) edt_list_planes(rowcnt, div, padded, planelist, counters, next_counters, (int)threadIdx.x);
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict
             env_add(E, g, e, u, __mul24(gd, gd), div);
         }
     }
-    env_finish(E, g, e, e.deepest + 1, &counters[3]);
+    env_finish(E, g, e, e.deepest + 1, report ? &counters[3] : nullptr);
     __syncthreads();
     env_write(E, g, plane + (size_t)x * div * div, (size_t)div, (unsigned)z, div);
 }
@@ -527,7 +527,7 @@ constexpr int EDT_PF = 8;
 template <int G, bool POOL>
 __global__ __launch_bounds__(64 * G) void k_edt_pass_x(const int* __restrict__ plane, const int* __restrict__ planelist,
                                                        u64* __restrict__ counters, int* __restrict__ sq, uint2* __restrict__ spill_buf,
-                                                       int div, int nchunk, int cap, int nch) {
+                                                       int div, int nchunk, int cap, int nch, int report) {
     extern __shared__ unsigned lds[];
     const int y = blockIdx.x / nchunk, c = blockIdx.x % nchunk;
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_x(const int* __restrict__ p
         for (int j = 0; j < EDT_PF; j++)
             if (k0 + j < khi) env_add(E, g, e, Uc[j], Gc[j], div);
     }
-    env_finish(E, g, e, e.deepest + 1, &counters[7]);
+    env_finish(E, g, e, e.deepest + 1, report ? &counters[7] : nullptr);
     __syncthreads();
     env_write(E, g, sq, xs, (unsigned)rowoff, div);
 }
@@ -640,7 +640,10 @@ static void edt_launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t 
 }
 
 // ev: NULL, or 2 * ICPX_EDT_NSTAGES events, a (start, stop) pair per stage: splat, census, pass zy, pass x.
-static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
+// report: the passes also record the deepest stack they saw (read back by the checked builds, which shape
+// the LDS of later ones with it; 6000 waves polling one counter cost 12 us per build, so rebuilds of the
+// same data skip it).
+static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev, int report) {
     const int div = (int)ctx->div, W = ctx->edt_words;
     const int nchunk = (div + 63) / 64;
     hipStream_t s = ctx->stream;
@@ -666,7 +669,7 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
                        : (G == 1 ? k_edt_pass_zy<1, false> : G == 2 ? k_edt_pass_zy<2, false> : G == 3 ? k_edt_pass_zy<3, false> : k_edt_pass_zy<4, false>);
         edt_launch(zy, dim3(div * nchunk + 1), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ev, 2, (const RowRec*)ctx->edt_rowlist.as<RowRec>(),
                    (const int*)ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, counters, div, W, cap, nch,
-                   edt_counter_set(ctx, ctx->edt_epoch ^ 1), (div + 15) / 16 * 16 + 16, ctx->edt_planelist.as<int>());
+                   edt_counter_set(ctx, ctx->edt_epoch ^ 1), (div + 15) / 16 * 16 + 16, ctx->edt_planelist.as<int>(), report);
     }
     {
         const int G = ctx->edt_x.groups, cap = ctx->edt_x.cap, nch = ctx->edt_x.chunks;
@@ -674,12 +677,12 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev) {
         auto px = pool ? (G == 1 ? k_edt_pass_x<1, true> : G == 2 ? k_edt_pass_x<2, true> : G == 3 ? k_edt_pass_x<3, true> : k_edt_pass_x<4, true>)
                        : (G == 1 ? k_edt_pass_x<1, false> : G == 2 ? k_edt_pass_x<2, false> : G == 3 ? k_edt_pass_x<3, false> : k_edt_pass_x<4, false>);
         edt_launch(px, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ev, 3, (const int*)ctx->edt_plane.as<int>(),
-                   (const int*)ctx->edt_planelist.as<int>(), counters, ctx->edt_sq.as<int>(), spill, div, nchunk, cap, nch);
+                   (const int*)ctx->edt_planelist.as<int>(), counters, ctx->edt_sq.as<int>(), spill, div, nchunk, cap, nch, report);
     }
     return icpx_launch_check(ctx, "EDT kernels");
 }
 
-int icpx_edt_run(icpx_ctx* ctx) { return edt_run_impl(ctx, nullptr); }
+int icpx_edt_run(icpx_ctx* ctx, bool report) { return edt_run_impl(ctx, nullptr, report ? 1 : 0); }
 
 extern "C" int icpx_edt_rebuild_timed(icpx_ctx* ctx, int reps, int sample_every, float stage_ms[ICPX_EDT_NSTAGES], int* sampled) {
     if (!ctx) return ICPX_EINVAL;
@@ -691,7 +694,7 @@ extern "C" int icpx_edt_rebuild_timed(icpx_ctx* ctx, int reps, int sample_every,
     for (auto& e : ev) ICPX_CHECK_HIP(ctx, hipEventCreate(&e));
     int rc = ICPX_OK;
     for (int r = 0; r < reps && rc == ICPX_OK; r++)
-        rc = edt_run_impl(ctx, r % sample_every == 0 ? ev.data() + (size_t)(r / sample_every) * 2 * ICPX_EDT_NSTAGES : nullptr);
+        rc = edt_run_impl(ctx, r % sample_every == 0 ? ev.data() + (size_t)(r / sample_every) * 2 * ICPX_EDT_NSTAGES : nullptr, 0);
     if (rc == ICPX_OK) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { ctx->set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e)); rc = ICPX_EHIP; }
@@ -730,7 +733,7 @@ static int edt_prepare(icpx_ctx* ctx, uint32_t div) {
 // Runs the kernels until a build fits its stack storage (at most twice) and checks that the grid is not empty.
 static int edt_build_attempts(icpx_ctx* ctx) {
     for (int attempt = 0; attempt < 2; attempt++) {
-        ICPX_TRY(icpx_edt_run(ctx));
+        ICPX_TRY(icpx_edt_run(ctx, true));
         u64 counters[8];
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, edt_counters(ctx), sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
         ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -816,7 +819,7 @@ extern "C" int icpx_edt_rebuild_async(icpx_ctx* ctx) {
     if (!ctx) return ICPX_EINVAL;
     if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_rebuild_async: no EDT has been built yet");
     ICPX_TRY(icpx_bind(ctx));
-    return icpx_edt_run(ctx);
+    return icpx_edt_run(ctx, false);
 }
 
 extern "C" int icpx_edt_info(icpx_ctx* ctx, uint32_t* div, float min3[3], float* cell_len, uint64_t* occupied, uint64_t* dropped) {
