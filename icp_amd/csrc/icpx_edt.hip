@@ -208,7 +208,7 @@ struct Env {
     __device__ __forceinline__ unsigned short& depth(int g) const { return *reinterpret_cast<unsigned short*>(lds + (g * 64 + lane) * 2); }
     __device__ __forceinline__ unsigned& table(int g) const { return *reinterpret_cast<unsigned*>(lds + G * 128 + (g * 64 + lane) * 4); }
     __device__ __forceinline__ unsigned* counter() const { return reinterpret_cast<unsigned*>(lds + G * 384); }
-    // winning stack at the last position of every part [G][64] u8 (in the padding behind the counter)
+    // winning stack at the last position of every part of the read-back [parts <= 2 G][64] u8 (in the padding behind the counter)
     __device__ __forceinline__ unsigned char& winner(int g) const { return *reinterpret_cast<unsigned char*>(lds + G * 384 + 64 + g * 64 + lane); }
     // byte addresses of level 0 of group g for this lane
     __device__ __forceinline__ int wbase(int g) const { return off_w + g * cap * 256 + lane * 4; }
@@ -403,15 +403,16 @@ __device__ __forceinline__ void env_dispatch(int jlo, int n, const Env<G, POOL>&
 }
 
 // Writes positions [plo, phi) of this lane's row: out[p * stride + lane_off] = min over the G stacks;
-// wave g of the workgroup handles part g of the positions. Called by all waves (contains a barrier).
+// wave w of the workgroup handles part w of `parts` parts of the positions (parts = number of waves: the G
+// that scanned, plus, in pass zy, as many again that only help here). Called by all waves (contains a barrier).
 // Stack i holds sites left of those of stack j > i, so envelope_i(p) - envelope_j(p) grows with p and the
 // index of the stack that attains the minimum never decreases with p: the stacks that can matter inside
 // a part lie between a winner at the last position of the previous part (found by the previous wave) and
 // a winner at the part's own last position. The wave evaluates only the range of stacks that covers this
 // interval for all of its lanes (usually one or two of the G).
 template <int G, bool POOL>
-__device__ __forceinline__ void env_write(const Env<G, POOL>& E, int g, int* __restrict__ out, size_t stride, unsigned lane_off, int div) {
-    const int plo = div * g / G, phi = div * (g + 1) / G;
+__device__ __forceinline__ void env_write(const Env<G, POOL>& E, int g, int parts, int* __restrict__ out, size_t stride, unsigned lane_off, int div) {
+    const int plo = div * g / parts, phi = div * (g + 1) / parts;
     EnvCur cur[G];
     int jlo = 0, jhi = G - 1;
     if (G > 1) {
@@ -443,18 +444,19 @@ __device__ __forceinline__ void env_write(const Env<G, POOL>& E, int g, int* __r
     env_dispatch<G, POOL, 0, 1>(jlo, jhi - jlo + 1, E, cur, out, stride, lane_off, plo, phi - 1);
 }
 
-// LDS layout: header (depths, chunk tables, pool counter) padded so that reads two levels below level 0
-// of group 0 stay inside the allocation, then the private levels, then the pool.
-static inline int env_off_w(int G) { return G * 384 + 512; }
-static size_t env_lds_bytes(int G, int cap, int nch) { return (size_t)env_off_w(G) + (size_t)G * cap * 384 + (size_t)nch * ENV_CHUNK * 6; }
+// LDS layout: header (depths, chunk tables, pool counter, winners of up to 2 G parts) padded so that reads two
+// levels below level 0 of group 0 stay inside the allocation, then the private levels, then the pool.
+// parts: waves of the workgroup (one winner byte per lane each, behind the 64-byte counter slot)
+__host__ __device__ inline int env_off_w(int G, int parts) { const int pad = (64 + parts * 64 + 255) & ~255; return G * 384 + (pad < 512 ? 512 : pad); }
+static size_t env_lds_bytes(int G, int parts, int cap, int nch) { return (size_t)env_off_w(G, parts) + (size_t)G * cap * 384 + (size_t)nch * ENV_CHUNK * 6; }
 
 template <int G, bool POOL>
-__device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int cap, int nch, int lane, uint2* sp, int div, size_t rows, size_t row,
+__device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int parts, int cap, int nch, int lane, uint2* sp, int div, size_t rows, size_t row,
                                             u64* ovf, bool active) {
     Env<G, POOL> E;
     E.lds = reinterpret_cast<char*>(lds);
     E.cap = cap; E.nch = nch; E.lane = lane;
-    E.off_w = G * 384 + 512;
+    E.off_w = env_off_w(G, parts);
     E.off_t = E.off_w + G * cap * 256;
     E.off_pw = E.off_t + G * cap * 128;
     E.off_pt = E.off_pw + nch * ENV_CHUNK * 4;
@@ -470,8 +472,12 @@ __device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int cap, int nc
 // Workgroup = plane x, 64 consecutive z; lane = z. Sites are the plane's non-empty rows y; their records
 // are fetched 64 at a time (lane j holds record j of the wave's site range, one coalesced load, the next
 // block prefetched) and broadcast with v_readlane as the scan reaches them. Value = (distance along z)^2.
-template <int G, bool POOL>
-__global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict__ recs, const int* __restrict__ rowcnt,
+// RB = 2: as many waves again join after the scan and take half of the read-back positions each; they wait
+// at the barrier meanwhile. A workgroup lasts as long as one wave's scan plus read-back, and there are too
+// few workgroups (here: non-empty planes x chunks) for other waves to fill the SIMDs in the meantime, so a
+// shorter chain is a shorter pass.
+template <int G, bool POOL, int RB>
+__global__ __launch_bounds__(64 * G * RB) void k_edt_pass_zy(const RowRec* __restrict__ recs, const int* __restrict__ rowcnt,
                                                         int* __restrict__ plane, uint2* __restrict__ spill_buf, u64* __restrict__ counters,
                                                         int div, int W, int cap, int nch, u64* __restrict__ next_counters, int padded,
                                                         int* __restrict__ planelist, int report) {
@@ -487,34 +493,36 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict
     const bool active = c * 64 + lane < div;
     const int z = active ? c * 64 + lane : div - 1;
     const int zl = z & 63;
-    const Env<G, POOL> E = env_setup<G, POOL>(lds, cap, nch, lane, spill_buf, div, (size_t)div * div, (size_t)x * div + z, &counters[4], active);
+    const Env<G, POOL> E = env_setup<G, POOL>(lds, G * RB, cap, nch, lane, spill_buf, div, (size_t)div * div, (size_t)x * div + z, &counters[4], active);
 
-    const int klo = cnt * g / G, khi = cnt * (g + 1) / G;
-    const int4* rr4 = reinterpret_cast<const int4*>(recs + ((size_t)x * W + c) * div);
-    EnvTop e;
-    env_init(E, g, e);
-    int4 nxt = klo + lane < khi ? rr4[klo + lane] : make_int4(0, 0, 0, 0);
-    for (int k0 = klo; k0 < khi; k0 += 64) {
-        const int4 cur = nxt;
-        if (k0 + 64 + lane < khi) nxt = rr4[k0 + 64 + lane];
-        const int m = min(64, khi - k0);
-        for (int j = 0; j < m; j++) {
-            const unsigned lo = (unsigned)bcast(cur.x, j), hi = (unsigned)bcast(cur.y, j);
-            const unsigned ba = (unsigned)bcast(cur.z, j);
-            const int u = bcast(cur.w, j);
-            const u64 own = ((u64)hi << 32) | lo;
-            const int below = (int)(ba & 0xffff) - 1, above = (int)(ba >> 16);
-            const u64 md = own & (~0ull >> (63 - zl));
-            const u64 mu = own >> zl;
-            const int down = md ? zl - (63 - __clzll(md)) : (below >= 0 ? z - below : BIGD);
-            const int up = mu ? (__ffsll((long long)mu) - 1) : (above != 0xffff ? above - z : BIGD);
-            const int gd = min(down, up);
-            env_add(E, g, e, u, __mul24(gd, gd), div);
+    if (g < G) {
+        const int klo = cnt * g / G, khi = cnt * (g + 1) / G;
+        const int4* rr4 = reinterpret_cast<const int4*>(recs + ((size_t)x * W + c) * div);
+        EnvTop e;
+        env_init(E, g, e);
+        int4 nxt = klo + lane < khi ? rr4[klo + lane] : make_int4(0, 0, 0, 0);
+        for (int k0 = klo; k0 < khi; k0 += 64) {
+            const int4 cur = nxt;
+            if (k0 + 64 + lane < khi) nxt = rr4[k0 + 64 + lane];
+            const int m = min(64, khi - k0);
+            for (int j = 0; j < m; j++) {
+                const unsigned lo = (unsigned)bcast(cur.x, j), hi = (unsigned)bcast(cur.y, j);
+                const unsigned ba = (unsigned)bcast(cur.z, j);
+                const int u = bcast(cur.w, j);
+                const u64 own = ((u64)hi << 32) | lo;
+                const int below = (int)(ba & 0xffff) - 1, above = (int)(ba >> 16);
+                const u64 md = own & (~0ull >> (63 - zl));
+                const u64 mu = own >> zl;
+                const int down = md ? zl - (63 - __clzll(md)) : (below >= 0 ? z - below : BIGD);
+                const int up = mu ? (__ffsll((long long)mu) - 1) : (above != 0xffff ? above - z : BIGD);
+                const int gd = min(down, up);
+                env_add(E, g, e, u, __mul24(gd, gd), div);
+            }
         }
+        env_finish(E, g, e, e.deepest + 1, report ? &counters[3] : nullptr);
     }
-    env_finish(E, g, e, e.deepest + 1, report ? &counters[3] : nullptr);
     __syncthreads();
-    env_write(E, g, plane + (size_t)x * div * div, (size_t)div, (unsigned)z, div);
+    env_write(E, g, G * RB, plane + (size_t)x * div * div, (size_t)div, (unsigned)z, div);
 }
 
 // ---- pass x ---------------------------------------------------------------------------------------------
@@ -523,9 +531,13 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_zy(const RowRec* __restrict
 // the group loads need no bounds checks; indices are wave-uniform scalar loads, values one coalesced load
 // per plane).
 constexpr int EDT_PF = 8;
+// Read-back helpers of the default shape (4 site groups): 2 = as many waves again. Measured on the 300^3
+// bunny grid: pass zy 34.8 / 30.3 / 31.5 / 32.1 us and pass x 65.4 / 58.9 / 70.7 / 73.0 us for 1 / 2 / 3 / 4
+// (from 3 on a CU no longer holds three workgroups of pass x).
+constexpr int EDT_ZY_RB = 2, EDT_X_RB = 2;
 
-template <int G, bool POOL>
-__global__ __launch_bounds__(64 * G) void k_edt_pass_x(const int* __restrict__ plane, const int* __restrict__ planelist,
+template <int G, bool POOL, int RB>
+__global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restrict__ plane, const int* __restrict__ planelist,
                                                        u64* __restrict__ counters, int* __restrict__ sq, uint2* __restrict__ spill_buf,
                                                        int div, int nchunk, int cap, int nch, int report) {
     extern __shared__ unsigned lds[];
@@ -536,31 +548,33 @@ __global__ __launch_bounds__(64 * G) void k_edt_pass_x(const int* __restrict__ p
     const int np = (int)counters[2];
     const size_t xs = (size_t)div * div;                  // elements between consecutive x
     const int rowoff = y * div + z;
-    const Env<G, POOL> E = env_setup<G, POOL>(lds, cap, nch, lane, spill_buf, div, xs, (size_t)rowoff, &counters[5], active);
+    const Env<G, POOL> E = env_setup<G, POOL>(lds, G * RB, cap, nch, lane, spill_buf, div, xs, (size_t)rowoff, &counters[5], active);
 
-    const int klo = np * g / G, khi = np * (g + 1) / G;
-    EnvTop e;
-    env_init(E, g, e);
-    int Gn[EDT_PF], Un[EDT_PF];
-#pragma unroll
-    for (int j = 0; j < EDT_PF; j++) Un[j] = planelist[klo + j];
-#pragma unroll
-    for (int j = 0; j < EDT_PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
-    for (int k0 = klo; k0 < khi; k0 += EDT_PF) {
-        int Gc[EDT_PF], Uc[EDT_PF];
-#pragma unroll
-        for (int j = 0; j < EDT_PF; j++) { Gc[j] = Gn[j]; Uc[j] = Un[j]; }
-#pragma unroll
-        for (int j = 0; j < EDT_PF; j++) Un[j] = planelist[k0 + EDT_PF + j];
-#pragma unroll
+    if (g < G) {
+        const int klo = np * g / G, khi = np * (g + 1) / G;
+        EnvTop e;
+        env_init(E, g, e);
+        int Gn[EDT_PF], Un[EDT_PF];
+    #pragma unroll
+        for (int j = 0; j < EDT_PF; j++) Un[j] = planelist[klo + j];
+    #pragma unroll
         for (int j = 0; j < EDT_PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
-#pragma unroll
-        for (int j = 0; j < EDT_PF; j++)
-            if (k0 + j < khi) env_add(E, g, e, Uc[j], Gc[j], div);
+        for (int k0 = klo; k0 < khi; k0 += EDT_PF) {
+            int Gc[EDT_PF], Uc[EDT_PF];
+    #pragma unroll
+            for (int j = 0; j < EDT_PF; j++) { Gc[j] = Gn[j]; Uc[j] = Un[j]; }
+    #pragma unroll
+            for (int j = 0; j < EDT_PF; j++) Un[j] = planelist[k0 + EDT_PF + j];
+    #pragma unroll
+            for (int j = 0; j < EDT_PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
+    #pragma unroll
+            for (int j = 0; j < EDT_PF; j++)
+                if (k0 + j < khi) env_add(E, g, e, Uc[j], Gc[j], div);
+        }
+        env_finish(E, g, e, e.deepest + 1, report ? &counters[7] : nullptr);
     }
-    env_finish(E, g, e, e.deepest + 1, report ? &counters[7] : nullptr);
     __syncthreads();
-    env_write(E, g, sq, xs, (unsigned)rowoff, div);
+    env_write(E, g, G * RB, sq, xs, (unsigned)rowoff, div);
 }
 
 // ---- lookup (device function in icpx_edt_dev.h) ----
@@ -665,18 +679,19 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev, int report) {
     {
         const int G = ctx->edt_zy.groups, cap = ctx->edt_zy.cap, nch = ctx->edt_zy.chunks;
         const bool pool = nch > 0 || ctx->edt_overflowed;
-        auto zy = pool ? (G == 1 ? k_edt_pass_zy<1, true> : G == 2 ? k_edt_pass_zy<2, true> : G == 3 ? k_edt_pass_zy<3, true> : k_edt_pass_zy<4, true>)
-                       : (G == 1 ? k_edt_pass_zy<1, false> : G == 2 ? k_edt_pass_zy<2, false> : G == 3 ? k_edt_pass_zy<3, false> : k_edt_pass_zy<4, false>);
-        edt_launch(zy, dim3(div * nchunk + 1), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ev, 2, (const RowRec*)ctx->edt_rowlist.as<RowRec>(),
+        const int RB = G == 4 ? EDT_ZY_RB : 1;   // read-back helpers for the default shape only
+        auto zy = pool ? (G == 1 ? k_edt_pass_zy<1, true, 1> : G == 2 ? k_edt_pass_zy<2, true, 1> : G == 3 ? k_edt_pass_zy<3, true, 1> : k_edt_pass_zy<4, true, EDT_ZY_RB>)
+                       : (G == 1 ? k_edt_pass_zy<1, false, 1> : G == 2 ? k_edt_pass_zy<2, false, 1> : G == 3 ? k_edt_pass_zy<3, false, 1> : k_edt_pass_zy<4, false, EDT_ZY_RB>);
+        edt_launch(zy, dim3(div * nchunk + 1), dim3(64 * G * RB), env_lds_bytes(G, G * RB, cap, nch), s, ev, 2, (const RowRec*)ctx->edt_rowlist.as<RowRec>(),
                    (const int*)ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, counters, div, W, cap, nch,
                    edt_counter_set(ctx, ctx->edt_epoch ^ 1), (div + 15) / 16 * 16 + 16, ctx->edt_planelist.as<int>(), report);
     }
     {
         const int G = ctx->edt_x.groups, cap = ctx->edt_x.cap, nch = ctx->edt_x.chunks;
         const bool pool = nch > 0 || ctx->edt_overflowed;
-        auto px = pool ? (G == 1 ? k_edt_pass_x<1, true> : G == 2 ? k_edt_pass_x<2, true> : G == 3 ? k_edt_pass_x<3, true> : k_edt_pass_x<4, true>)
-                       : (G == 1 ? k_edt_pass_x<1, false> : G == 2 ? k_edt_pass_x<2, false> : G == 3 ? k_edt_pass_x<3, false> : k_edt_pass_x<4, false>);
-        edt_launch(px, dim3(div * nchunk), dim3(64 * G), env_lds_bytes(G, cap, nch), s, ev, 3, (const int*)ctx->edt_plane.as<int>(),
+        auto px = pool ? (G == 1 ? k_edt_pass_x<1, true, 1> : G == 2 ? k_edt_pass_x<2, true, 1> : G == 3 ? k_edt_pass_x<3, true, 1> : k_edt_pass_x<4, true, EDT_X_RB>)
+                       : (G == 1 ? k_edt_pass_x<1, false, 1> : G == 2 ? k_edt_pass_x<2, false, 1> : G == 3 ? k_edt_pass_x<3, false, 1> : k_edt_pass_x<4, false, EDT_X_RB>);
+        edt_launch(px, dim3(div * nchunk), dim3(64 * G * (G == 4 ? EDT_X_RB : 1)), env_lds_bytes(G, G * (G == 4 ? EDT_X_RB : 1), cap, nch), s, ev, 3, (const int*)ctx->edt_plane.as<int>(),
                    (const int*)ctx->edt_planelist.as<int>(), counters, ctx->edt_sq.as<int>(), spill, div, nchunk, cap, nch, report);
     }
     return icpx_launch_check(ctx, "EDT kernels");
