@@ -74,7 +74,7 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
         const char* v = getenv(k ? "ICPX_EDT_X" : "ICPX_EDT_ZY");
         int g = 0, c = 0, n = 0;
         if (v && sscanf(v, "%d,%d,%d", &g, &c, &n) == 3 && g >= 1 && g <= 4 && c >= 2 && n >= 0 && n <= 254 &&
-            g * 384 + 768 + g * c * 384 + n * 48 <= 65536)
+            g * 384 + 768 + g * (c + 1) * 384 + n * 48 <= 65536)
             { (k ? ctx->edt_x : ctx->edt_zy) = EnvTune{g, c, n}; ctx->edt_tune_fixed = true; }
     }
     *out = ctx;

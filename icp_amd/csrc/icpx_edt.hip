@@ -178,7 +178,8 @@ __device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70)
 // against all G stacks and takes the minimum. The stacks are never merged.
 //
 // A stack entry is {site s, a = s^2 + value} in one dword (s << 22 | a; a <= 3 (div - 1)^2 < 2^22 because
-// div <= 1023) and the first position t the entry owns among the entries of its own stack in a halfword. Where the levels live:
+// div <= 1023) and, in a halfword, twice the first position t the entry owns among the entries of its own
+// stack (doubled because every use is a comparison against or a product with 2 t). Where the levels live:
 //   level < cap                 LDS, [group][level][lane] (conflict-free)
 //   cap <= level < cap + 32     LDS pool shared by the workgroup: chunks of 8 levels, handed out with an
 //                               atomic counter the first time a stack reaches them; the four chunk ids of
@@ -196,7 +197,7 @@ template <int G, bool POOL>
 struct Env {
     char* lds;
     int cap, nch, lane;
-    int off_w, off_t, off_pw, off_pt;   // byte offsets: words [G][cap][64] u32, starts [G][cap][64] u16, pool words, pool starts
+    int off_w, off_t, off_pw, off_pt;   // byte offsets: words [G][ROWS][64] u32, starts [G][ROWS][64] u16, pool words, pool starts
     uint2* sp;               // spill buffer (already offset to this lane's row) or NULL
     int sp_levels;           // levels the spill buffer holds
     unsigned sp_stride;      // entries between consecutive levels of one stack (groups x rows of the pass)
@@ -204,15 +205,19 @@ struct Env {
     u64* ovf;                // overflow counter word
     bool active;             // lane owns a row (idle lanes shadow the last row and never store)
 
-    // LDS header: depths [G][64] u16, chunk tables [G][64] u32, pool counter
+    // LDS header: depths [G][64] u16, chunk tables [G][64] u32, pool counter.
+    // Without the pool every stack has one more row below its level 0: a sentinel entry {site 0, a 0,
+    // start 0} that no site can pop, so the scan needs no "stack empty" test.
+    static constexpr int FIRST = POOL ? 0 : 1;
+    __device__ __forceinline__ int rows() const { return cap + FIRST; }
     __device__ __forceinline__ unsigned short& depth(int g) const { return *reinterpret_cast<unsigned short*>(lds + (g * 64 + lane) * 2); }
     __device__ __forceinline__ unsigned& table(int g) const { return *reinterpret_cast<unsigned*>(lds + G * 128 + (g * 64 + lane) * 4); }
     __device__ __forceinline__ unsigned* counter() const { return reinterpret_cast<unsigned*>(lds + G * 384); }
     // winning stack at the last position of every part of the read-back [parts <= 2 G][64] u8 (in the padding behind the counter)
-    __device__ __forceinline__ unsigned char& winner(int g) const { return *reinterpret_cast<unsigned char*>(lds + G * 384 + 64 + g * 64 + lane); }
+    __device__ __forceinline__ unsigned char& winner(int g) const { return *reinterpret_cast<unsigned char*>(lds + (POOL ? G * 384 + 64 : G * 128) + g * 64 + lane); }
     // byte addresses of level 0 of group g for this lane
-    __device__ __forceinline__ int wbase(int g) const { return off_w + g * cap * 256 + lane * 4; }
-    __device__ __forceinline__ int tbase(int g) const { return off_t + g * cap * 128 + lane * 2; }
+    __device__ __forceinline__ int wbase(int g) const { return off_w + (g * rows() + FIRST) * 256 + lane * 4; }
+    __device__ __forceinline__ int tbase(int g) const { return off_t + (g * rows() + FIRST) * 128 + lane * 2; }
     __device__ __forceinline__ unsigned& W(int wb, int level) const { return *reinterpret_cast<unsigned*>(lds + wb + (level << 8)); }
     __device__ __forceinline__ unsigned short& T(int tb, int level) const { return *reinterpret_cast<unsigned short*>(lds + tb + (level << 7)); }
     __device__ __forceinline__ size_t spslot(int g, int level) const { return (size_t)(unsigned)(level - cap) * sp_stride + (size_t)g * sp_gstride; }
@@ -264,17 +269,24 @@ struct Env {
 // Scan state of one stack: the top entry unpacked, the entry below it packed.
 struct EnvTop {
     int q;                  // index of the top entry, -1 = empty
-    int ts, ta, tt2;        // top: site, a = s^2 + value, twice its start
-    unsigned tw; int tt;    // top, packed, and its start
-    unsigned bw; int bt;    // entry below the top (undefined when q < 1)
-    int wb, tb;             // LDS byte addresses of level 0 of this stack
+    unsigned tw; int tt2;   // top, packed, and twice its start
+    unsigned bw; int bt2;   // entry below the top (undefined when q < 1)
+    int wb, tb;             // byte offsets of level 0 of this stack in the workgroup's LDS block
     unsigned tab;           // pool chunk ids of this stack
     int deepest;            // largest q so far
+    unsigned aw, at;        // LDS addresses of level -1 (words, starts), for the hand-written pop loop
 };
+
+// 32-bit LDS address of a pointer into the workgroup's LDS block
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
 
 template <int G, bool POOL>
 __device__ __forceinline__ void env_init(const Env<G, POOL>& E, int g, EnvTop& e) {
-    e = EnvTop{-1, 0, 0, 0, 0u, 0, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu, -1};
+    e = EnvTop{-1, 0u, 0, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu, -1, 0u, 0u};
+    e.aw = lds_address(E.lds + e.wb - 256); e.at = lds_address(E.lds + e.tb - 128);
+    if (!POOL) { E.W(e.wb, -1) = 0u; E.T(e.tb, -1) = 0; }   // the sentinel below level 0
 }
 
 // Adds site u (ascending) with value v to the stack of group g: pop while the new parabola is lower at
@@ -286,22 +298,68 @@ __device__ __forceinline__ void env_init(const Env<G, POOL>& E, int g, EnvTop& e
 template <int G, bool POOL>
 __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e, int u, int v, int div) {
     const int au = (u & 0x3ff) * (u & 0x3ff) + v;
-    int d, dd;
-    for (;;) {
-        d = u - e.ts; dd = e.ta - au;
-        if (!(e.q >= 0 && __mul24(e.tt2, d) + dd > 0)) break;
-        e.tw = e.bw; e.ts = (int)(e.bw >> ENV_VB); e.ta = (int)(e.bw & ENV_VMASK); e.tt = e.bt; e.tt2 = 2 * e.bt;
-        e.q--;
-        E.load(g, e.wb, e.tb, e.tab, e.q - 1, e.bw, e.bt);
+    int d, dd, w;
+    if constexpr (!POOL) {
+        // The pop loop and the crossing, by hand. The loop runs while any lane of the wave has to pop and is
+        // predicated instead of divergent (lanes that are done re-read the entry they already hold): 16
+        // instructions per round where the compiled divergent loop needs about 30, most of them mask
+        // bookkeeping, and a wave issues one instruction every eight cycles or so whatever its kind. The
+        // sentinel row makes "stack empty" a case of the same test: 0 * d + (0 - au) > 0 is false. The
+        // compiler does not see the LDS reads in here, so the block ends with the wait for them, placed
+        // behind the crossing's arithmetic, which covers most of their latency.
+        int x, y;
+        asm volatile(
+            "Lenv_pop_%=:\n"
+            "v_lshrrev_b32 %[d], 22, %[tw]\n"
+            "v_and_b32 %[dd], 0x3fffff, %[tw]\n"
+            "v_sub_u32 %[d], %[u], %[d]\n"
+            "v_sub_u32 %[dd], %[dd], %[au]\n"
+            "v_mad_i32_i24 %[x], %[tt2], %[d], %[dd]\n"
+            "v_cmp_lt_i32 vcc, 0, %[x]\n"
+            "s_cbranch_vccz Lenv_done_%=\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_cndmask_b32 %[tw], %[tw], %[bw], vcc\n"
+            "v_cndmask_b32 %[tt2], %[tt2], %[bt2], vcc\n"
+            "v_subbrev_co_u32 %[q], vcc, 0, %[q], vcc\n"
+            "v_lshl_add_u32 %[x], %[q], 8, %[aw]\n"
+            "v_lshl_add_u32 %[y], %[q], 7, %[at]\n"
+            "ds_read_b32 %[bw], %[x]\n"
+            "ds_read_u16 %[bt2], %[y]\n"
+            "s_branch Lenv_pop_%=\n"
+            "Lenv_done_%=:\n"
+            // crossing: w = 1 + floor((2 N + 1) / (2 D)) with N = -dd, D = 2 d (floordiv_pos), then the wait for the
+            // last read-back, which these instructions have covered
+            "v_mad_i32_i24 %[x], %[dd], -2, 1\n"
+            "v_lshlrev_b32 %[y], 2, %[d]\n"
+            "v_cvt_f32_i32 %[x], %[x]\n"
+            "v_cvt_f32_i32 %[y], %[y]\n"
+            "v_rcp_f32 %[y], %[y]\n"
+            "s_nop 0\n"
+            "v_mul_f32 %[x], %[x], %[y]\n"
+            "v_cvt_i32_f32 %[x], %[x]\n"
+            "v_add_u32 %[w], 1, %[x]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            : [tw] "+v"(e.tw), [tt2] "+v"(e.tt2), [bw] "+v"(e.bw), [bt2] "+v"(e.bt2), [q] "+v"(e.q), [d] "=&v"(d), [dd] "=&v"(dd),
+              [x] "=&v"(x), [y] "=&v"(y), [w] "=&v"(w)
+            : [u] "s"(u), [au] "v"(au), [aw] "v"(e.aw), [at] "v"(e.at)
+            : "vcc", "memory");
+    } else {
+        for (;;) {
+            d = u - (int)(e.tw >> ENV_VB); dd = (int)(e.tw & ENV_VMASK) - au;
+            if (!(e.q >= 0 && __mul24(e.tt2, d) + dd > 0)) break;
+            e.tw = e.bw; e.tt2 = e.bt2;
+            e.q--;
+            E.load(g, e.wb, e.tb, e.tab, e.q - 1, e.bw, e.bt2);
+        }
+        w = 1 + floordiv_pos(-dd, 2 * d);
     }
-    int w = 1 + floordiv_pos(-dd, 2 * d);
     if (e.q < 0) w = 0;
     if (w < div) {
-        e.bw = e.tw; e.bt = e.tt;
-        e.tw = ((unsigned)u << ENV_VB) | (unsigned)au; e.ts = u; e.ta = au; e.tt = w; e.tt2 = 2 * w;
+        e.bw = e.tw; e.bt2 = e.tt2;
+        e.tw = ((unsigned)u << ENV_VB) | (unsigned)au; e.tt2 = 2 * w;
         e.q++;
         e.deepest = max(e.deepest, e.q);
-        E.store(g, e.wb, e.tb, e.tab, e.q, e.tw, w);
+        E.store(g, e.wb, e.tb, e.tab, e.q, e.tw, e.tt2);
     }
 }
 
@@ -314,14 +372,14 @@ __device__ __forceinline__ void env_finish(const Env<G, POOL>& E, int g, EnvTop&
     if (max_depth && E.lane == 0 && (u64)deepest > *(volatile u64*)max_depth) atomicMax(max_depth, (u64)deepest);
     if (e.q < 0) { e.q = 0; E.store(g, e.wb, e.tb, e.tab, 0, ENV_VMASK, 0); }
     E.depth(g) = (unsigned short)e.q;
-    E.table(g) = e.tab;
+    if (POOL) E.table(g) = e.tab;
 }
 
 // Evaluation cursor on one stack, walking towards position 0.
 struct EnvCur {
     int lvl;                // level of the current entry
-    unsigned cw; int ct;    // current entry
-    unsigned bw; int bt;    // entry one level below (whatever precedes the stack in LDS when lvl == 0: never used)
+    unsigned cw; int ct2;   // current entry (start doubled, as stored)
+    unsigned bw; int bt2;   // entry one level below (whatever precedes the stack in LDS when lvl == 0: never used)
     int wb, tb;             // LDS byte addresses of level 0 of the stack
     unsigned tab;
 };
@@ -329,17 +387,17 @@ struct EnvCur {
 // Positions the cursor on the entry of group j that owns position p (largest level whose start is <= p).
 template <int G, bool POOL>
 __device__ __forceinline__ void env_seek(const Env<G, POOL>& E, int j, EnvCur& c, int p) {
-    c.wb = E.wbase(j); c.tb = E.tbase(j); c.tab = E.table(j);
+    c.wb = E.wbase(j); c.tb = E.tbase(j); c.tab = POOL ? E.table(j) : 0xffffffffu;
     int lo = 0, hi = E.depth(j);
     while (lo < hi) {
         const int m = (lo + hi + 1) >> 1;
-        unsigned w; int t;
-        E.load(j, c.wb, c.tb, c.tab, m, w, t);
-        if (t <= p) lo = m; else hi = m - 1;
+        unsigned w; int t2;
+        E.load(j, c.wb, c.tb, c.tab, m, w, t2);
+        if (t2 <= 2 * p) lo = m; else hi = m - 1;
     }
     c.lvl = lo;
-    E.load(j, c.wb, c.tb, c.tab, lo, c.cw, c.ct);
-    E.load(j, c.wb, c.tb, c.tab, lo - 1, c.bw, c.bt);
+    E.load(j, c.wb, c.tb, c.tab, lo, c.cw, c.ct2);
+    E.load(j, c.wb, c.tb, c.tab, lo - 1, c.bw, c.bt2);
 }
 
 // f(p) - p^2 of the entry under the cursor: a 24-bit multiply-add
@@ -353,12 +411,12 @@ __device__ __forceinline__ int env_value(const EnvCur& c, int p) {
 // HIGH: some lane's cursor may still be above the private levels.
 template <int G, bool POOL, bool HIGH>
 __device__ __forceinline__ void env_step(const Env<G, POOL>& E, int j, EnvCur& c, int p) {
-    const bool down = p == c.ct;
+    const bool down = 2 * p == c.ct2;
     c.cw = down ? c.bw : c.cw;
-    c.ct = down ? c.bt : c.ct;
+    c.ct2 = down ? c.bt2 : c.ct2;
     c.lvl -= down ? 1 : 0;
-    if (HIGH) E.load(j, c.wb, c.tb, c.tab, c.lvl - 1, c.bw, c.bt);
-    else { c.bw = E.W(c.wb - 256, c.lvl); c.bt = E.T(c.tb - 128, c.lvl); }
+    if (HIGH) E.load(j, c.wb, c.tb, c.tab, c.lvl - 1, c.bw, c.bt2);
+    else { c.bw = E.W(c.wb - 256, c.lvl); c.bt2 = E.T(c.tb - 128, c.lvl); }
 }
 
 // Positions [plo, p] of this lane's row from stacks LO .. LO + N - 1 only.
@@ -447,8 +505,13 @@ __device__ __forceinline__ void env_write(const Env<G, POOL>& E, int g, int part
 // LDS layout: header (depths, chunk tables, pool counter, winners of up to 2 G parts) padded so that reads two
 // levels below level 0 of group 0 stay inside the allocation, then the private levels, then the pool.
 // parts: waves of the workgroup (one winner byte per lane each, behind the 64-byte counter slot)
-__host__ __device__ inline int env_off_w(int G, int parts) { const int pad = (64 + parts * 64 + 255) & ~255; return G * 384 + (pad < 512 ? 512 : pad); }
-static size_t env_lds_bytes(int G, int parts, int cap, int nch) { return (size_t)env_off_w(G, parts) + (size_t)G * cap * 384 + (size_t)nch * ENV_CHUNK * 6; }
+// Without the pool the header is just depths and winners (no chunk tables, no counter).
+__host__ __device__ inline int env_off_w(int G, int parts, bool pool) {
+    if (!pool) { const int h = G * 128 + parts * 64; return h < 512 ? 512 : h; }
+    const int pad = (64 + parts * 64 + 255) & ~255;
+    return G * 384 + (pad < 512 ? 512 : pad);
+}
+static size_t env_lds_bytes(int G, int parts, int cap, int nch, bool pool) { return (size_t)env_off_w(G, parts, pool) + (size_t)G * (cap + (pool ? 0 : 1)) * 384 + (size_t)nch * ENV_CHUNK * 6; }
 
 template <int G, bool POOL>
 __device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int parts, int cap, int nch, int lane, uint2* sp, int div, size_t rows, size_t row,
@@ -456,15 +519,17 @@ __device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int parts, int 
     Env<G, POOL> E;
     E.lds = reinterpret_cast<char*>(lds);
     E.cap = cap; E.nch = nch; E.lane = lane;
-    E.off_w = env_off_w(G, parts);
-    E.off_t = E.off_w + G * cap * 256;
-    E.off_pw = E.off_t + G * cap * 128;
+    E.off_w = env_off_w(G, parts, POOL);
+    E.off_t = E.off_w + G * E.rows() * 256;
+    E.off_pw = E.off_t + G * E.rows() * 128;
     E.off_pt = E.off_pw + nch * ENV_CHUNK * 4;
     E.sp = sp ? sp + row : nullptr;
     E.sp_levels = max((div + G - 1) / G + 1 - cap, 1);   // the host sizes the buffer with the same rule
     E.sp_gstride = (unsigned)rows; E.sp_stride = (unsigned)rows * G; E.ovf = ovf; E.active = active;
-    if (threadIdx.x == 0) *E.counter() = 0;
-    __syncthreads();
+    if (POOL) {
+        if (threadIdx.x == 0) *E.counter() = 0;
+        __syncthreads();
+    }
     return E;
 }
 
@@ -633,7 +698,7 @@ static size_t edt_spill_bytes(const icpx_ctx* ctx) {
 static void edt_adapt(icpx_ctx* ctx, u64 deepest_zy, u64 deepest_x) {
     if (ctx->edt_tune_fixed) return;
     const EnvTune def{4, 28, 40};
-    const int cap_max = 33;   // 4 groups x 33 levels x 384 B + header = 52 KiB: three workgroups per CU
+    const int cap_max = 33;   // 4 groups x (33 + 1 sentinel) rows x 384 B + 1 KiB header = 52 KiB: three workgroups per CU
     const u64 d[2] = {deepest_zy, deepest_x};
     EnvTune* t[2] = {&ctx->edt_zy, &ctx->edt_x};
     bool fits = true;
@@ -682,7 +747,7 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev, int report) {
         const int RB = G == 4 ? EDT_ZY_RB : 1;   // read-back helpers for the default shape only
         auto zy = pool ? (G == 1 ? k_edt_pass_zy<1, true, 1> : G == 2 ? k_edt_pass_zy<2, true, 1> : G == 3 ? k_edt_pass_zy<3, true, 1> : k_edt_pass_zy<4, true, EDT_ZY_RB>)
                        : (G == 1 ? k_edt_pass_zy<1, false, 1> : G == 2 ? k_edt_pass_zy<2, false, 1> : G == 3 ? k_edt_pass_zy<3, false, 1> : k_edt_pass_zy<4, false, EDT_ZY_RB>);
-        edt_launch(zy, dim3(div * nchunk + 1), dim3(64 * G * RB), env_lds_bytes(G, G * RB, cap, nch), s, ev, 2, (const RowRec*)ctx->edt_rowlist.as<RowRec>(),
+        edt_launch(zy, dim3(div * nchunk + 1), dim3(64 * G * RB), env_lds_bytes(G, G * RB, cap, nch, pool), s, ev, 2, (const RowRec*)ctx->edt_rowlist.as<RowRec>(),
                    (const int*)ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, counters, div, W, cap, nch,
                    edt_counter_set(ctx, ctx->edt_epoch ^ 1), (div + 15) / 16 * 16 + 16, ctx->edt_planelist.as<int>(), report);
     }
@@ -691,7 +756,7 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev, int report) {
         const bool pool = nch > 0 || ctx->edt_overflowed;
         auto px = pool ? (G == 1 ? k_edt_pass_x<1, true, 1> : G == 2 ? k_edt_pass_x<2, true, 1> : G == 3 ? k_edt_pass_x<3, true, 1> : k_edt_pass_x<4, true, EDT_X_RB>)
                        : (G == 1 ? k_edt_pass_x<1, false, 1> : G == 2 ? k_edt_pass_x<2, false, 1> : G == 3 ? k_edt_pass_x<3, false, 1> : k_edt_pass_x<4, false, EDT_X_RB>);
-        edt_launch(px, dim3(div * nchunk), dim3(64 * G * (G == 4 ? EDT_X_RB : 1)), env_lds_bytes(G, G * (G == 4 ? EDT_X_RB : 1), cap, nch), s, ev, 3, (const int*)ctx->edt_plane.as<int>(),
+        edt_launch(px, dim3(div * nchunk), dim3(64 * G * (G == 4 ? EDT_X_RB : 1)), env_lds_bytes(G, G * (G == 4 ? EDT_X_RB : 1), cap, nch, pool), s, ev, 3, (const int*)ctx->edt_plane.as<int>(),
                    (const int*)ctx->edt_planelist.as<int>(), counters, ctx->edt_sq.as<int>(), spill, div, nchunk, cap, nch, report);
     }
     return icpx_launch_check(ctx, "EDT kernels");
