@@ -305,8 +305,9 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
         // instructions per round where the compiled divergent loop needs about 30, most of them mask
         // bookkeeping, and a wave issues one instruction every eight cycles or so whatever its kind. The
         // sentinel row makes "stack empty" a case of the same test: 0 * d + (0 - au) > 0 is false. The
-        // compiler does not see the LDS reads in here, so the block ends with the wait for them, placed
-        // behind the crossing's arithmetic, which covers most of their latency.
+        // push follows as straight-line selects. The compiler does not see the LDS traffic in here: the wait for
+        // the loop's last read-back sits behind the crossing's arithmetic, which covers most of its latency,
+        // and the writes need none (LDS operations of a wave complete in order).
         int x, y;
         asm volatile(
             "Lenv_pop_%=:\n"
@@ -327,8 +328,7 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
             "ds_read_u16 %[bt2], %[y]\n"
             "s_branch Lenv_pop_%=\n"
             "Lenv_done_%=:\n"
-            // crossing: w = 1 + floor((2 N + 1) / (2 D)) with N = -dd, D = 2 d (floordiv_pos), then the wait for the
-            // last read-back, which these instructions have covered
+            // crossing: w = 1 + floor((2 N + 1) / (2 D)) with N = -dd, D = 2 d (floordiv_pos)
             "v_mad_i32_i24 %[x], %[dd], -2, 1\n"
             "v_lshlrev_b32 %[y], 2, %[d]\n"
             "v_cvt_f32_i32 %[x], %[x]\n"
@@ -338,11 +338,31 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
             "v_mul_f32 %[x], %[x], %[y]\n"
             "v_cvt_i32_f32 %[x], %[x]\n"
             "v_add_u32 %[w], 1, %[x]\n"
+            // an empty stack takes the site from position 0; the site enters if its first position is inside the row
+            "v_cmp_gt_i32 vcc, 0, %[q]\n"
+            "v_cndmask_b32_e64 %[w], %[w], 0, vcc\n"
+            "v_lshl_or_b32 %[x], %[u], 22, %[au]\n"
+            "v_lshlrev_b32 %[y], 1, %[w]\n"
+            "v_cmp_gt_i32 vcc, %[div], %[w]\n"
             "s_waitcnt lgkmcnt(0)\n"
-            : [tw] "+v"(e.tw), [tt2] "+v"(e.tt2), [bw] "+v"(e.bw), [bt2] "+v"(e.bt2), [q] "+v"(e.q), [d] "=&v"(d), [dd] "=&v"(dd),
-              [x] "=&v"(x), [y] "=&v"(y), [w] "=&v"(w)
-            : [u] "s"(u), [au] "v"(au), [aw] "v"(e.aw), [at] "v"(e.at)
+            "v_cndmask_b32 %[bw], %[bw], %[tw], vcc\n"
+            "v_cndmask_b32 %[bt2], %[bt2], %[tt2], vcc\n"
+            "v_cndmask_b32 %[tw], %[tw], %[x], vcc\n"
+            "v_cndmask_b32 %[tt2], %[tt2], %[y], vcc\n"
+            "v_addc_co_u32 %[q], vcc, 0, %[q], vcc\n"
+            "v_max_i32 %[deep], %[deep], %[q]\n"
+            // every lane writes its top entry (lanes that did not push rewrite what is there); the level is
+            // clamped to the last private one, a stack that got there is reported by env_finish
+            "v_min_i32 %[d], %[capm1], %[q]\n"
+            "v_lshl_add_u32 %[dd], %[d], 8, %[aw]\n"
+            "v_lshl_add_u32 %[d], %[d], 7, %[at]\n"
+            "ds_write_b32 %[dd], %[tw] offset:256\n"
+            "ds_write_b16 %[d], %[tt2] offset:128\n"
+            : [tw] "+v"(e.tw), [tt2] "+v"(e.tt2), [bw] "+v"(e.bw), [bt2] "+v"(e.bt2), [q] "+v"(e.q), [deep] "+v"(e.deepest),
+              [d] "=&v"(d), [dd] "=&v"(dd), [x] "=&v"(x), [y] "=&v"(y), [w] "=&v"(w)
+            : [u] "s"(u), [au] "v"(au), [aw] "v"(e.aw), [at] "v"(e.at), [div] "s"(div), [capm1] "s"(E.cap - 1)
             : "vcc", "memory");
+        return;
     } else {
         for (;;) {
             d = u - (int)(e.tw >> ENV_VB); dd = (int)(e.tw & ENV_VMASK) - au;
@@ -370,6 +390,7 @@ template <int G, bool POOL>
 __device__ __forceinline__ void env_finish(const Env<G, POOL>& E, int g, EnvTop& e, int deepest, u64* max_depth) {
     for (int o = 32; o; o >>= 1) deepest = max(deepest, __shfl_xor(deepest, o));
     if (max_depth && E.lane == 0 && (u64)deepest > *(volatile u64*)max_depth) atomicMax(max_depth, (u64)deepest);
+    if (!POOL && e.deepest >= E.cap) *E.ovf = 1;   // the hand-written scan clamps instead of checking every push
     if (e.q < 0) { e.q = 0; E.store(g, e.wb, e.tb, e.tab, 0, ENV_VMASK, 0); }
     E.depth(g) = (unsigned short)e.q;
     if (POOL) E.table(g) = e.tab;
