@@ -203,7 +203,7 @@ struct Env {
     unsigned sp_stride;      // entries between consecutive levels of one stack (groups x rows of the pass)
     unsigned sp_gstride;     // entries between the stacks of consecutive groups (rows of the pass)
     u64* ovf;                // overflow counter word
-    bool active;             // lane owns a row (idle lanes shadow the last row and never store)
+    bool active;             // lane owns a row (idle lanes shadow the last row: whatever they store, that row's lane stores too)
 
     // LDS header: depths [G][64] u16, chunk tables [G][64] u32, pool counter.
     // Without the pool every stack has one more row below its level 0: a sentinel entry {site 0, a 0,
@@ -256,7 +256,7 @@ struct Env {
         if (ps >= 0) {
             *reinterpret_cast<unsigned*>(lds + off_pw + ps * 4) = w;
             *reinterpret_cast<unsigned short*>(lds + off_pt + ps * 2) = (unsigned short)t;
-        } else if (sp && level - cap < sp_levels) { if (active) sp[spslot(g, level)] = make_uint2(w, (unsigned)t); }
+        } else if (sp && level - cap < sp_levels) sp[spslot(g, level)] = make_uint2(w, (unsigned)t);   // idle lanes too: same slot, same entry as the row they shadow
         else *ovf = 1;
     }
     __device__ __forceinline__ void store(int g, int wb, int tb, unsigned& tab, int level, unsigned w, int t) const {
@@ -452,7 +452,7 @@ __device__ __forceinline__ void env_span(const Env<G, POOL>& E, EnvCur (&cur)[G]
         int v = 0x7fffffff;
 #pragma unroll
         for (int j = LO; j < LO + N; j++) v = min(v, env_value(cur[j], p));
-        if (E.active) (out + (size_t)p * stride)[lane_off] = v + p * p;
+        (out + (size_t)p * stride)[lane_off] = v + p * p;   // idle lanes shadow the last row: same value, same address
 #pragma unroll
         for (int j = LO; j < LO + N; j++) {   // only the stacks that are still above pay for the general read-back
             if (__any(cur[j].lvl >= E.cap)) env_step<G, POOL, true>(E, j, cur[j], p);
@@ -465,7 +465,7 @@ __device__ __forceinline__ void env_span(const Env<G, POOL>& E, EnvCur (&cur)[G]
         int v = 0x7fffffff;
 #pragma unroll
         for (int j = LO; j < LO + N; j++) v = min(v, env_value(cur[j], p));
-        if (E.active) (out + (size_t)p * stride)[lane_off] = v + p * p;
+        (out + (size_t)p * stride)[lane_off] = v + p * p;   // idle lanes shadow the last row: same value, same address
 #pragma unroll
         for (int j = LO; j < LO + N; j++) env_step<G, POOL, false>(E, j, cur[j], p);
     }
