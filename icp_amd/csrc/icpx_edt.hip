@@ -203,7 +203,6 @@ struct Env {
     unsigned sp_stride;      // entries between consecutive levels of one stack (groups x rows of the pass)
     unsigned sp_gstride;     // entries between the stacks of consecutive groups (rows of the pass)
     u64* ovf;                // overflow counter word
-    bool active;             // lane owns a row (idle lanes shadow the last row: whatever they store, that row's lane stores too)
 
     // LDS header: depths [G][64] u16, chunk tables [G][64] u32, pool counter.
     // Without the pool every stack has one more row below its level 0: a sentinel entry {site 0, a 0,
@@ -423,7 +422,7 @@ __device__ __forceinline__ void env_seek(const Env<G, POOL>& E, int j, EnvCur& c
 
 // f(p) - p^2 of the entry under the cursor: a 24-bit multiply-add
 __device__ __forceinline__ int env_value(const EnvCur& c, int p) {
-    return (int)(c.cw >> ENV_VB) * (-2 * (p & 0x3ff)) + (int)(c.cw & ENV_VMASK);
+    return __mul24((int)(c.cw >> ENV_VB), -2 * p) + (int)(c.cw & ENV_VMASK);   // 0 <= p <= 1022
 }
 
 // One level down if p was the first position of the current entry. The entry below is already in
@@ -536,7 +535,7 @@ static size_t env_lds_bytes(int G, int parts, int cap, int nch, bool pool) { ret
 
 template <int G, bool POOL>
 __device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int parts, int cap, int nch, int lane, uint2* sp, int div, size_t rows, size_t row,
-                                            u64* ovf, bool active) {
+                                            u64* ovf) {
     Env<G, POOL> E;
     E.lds = reinterpret_cast<char*>(lds);
     E.cap = cap; E.nch = nch; E.lane = lane;
@@ -546,7 +545,7 @@ __device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int parts, int 
     E.off_pt = E.off_pw + nch * ENV_CHUNK * 4;
     E.sp = sp ? sp + row : nullptr;
     E.sp_levels = max((div + G - 1) / G + 1 - cap, 1);   // the host sizes the buffer with the same rule
-    E.sp_gstride = (unsigned)rows; E.sp_stride = (unsigned)rows * G; E.ovf = ovf; E.active = active;
+    E.sp_gstride = (unsigned)rows; E.sp_stride = (unsigned)rows * G; E.ovf = ovf;
     if (POOL) {
         if (threadIdx.x == 0) *E.counter() = 0;
         __syncthreads();
@@ -576,10 +575,9 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_zy(const RowRec* __res
     const int cnt = rowcnt[x];
     if (cnt == 0) return;   // plane without voxels: never read by pass x
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool active = c * 64 + lane < div;
-    const int z = active ? c * 64 + lane : div - 1;
+    const int z = min(c * 64 + lane, div - 1);   // lanes beyond the row's end shadow its last voxel: same work, same stores
     const int zl = z & 63;
-    const Env<G, POOL> E = env_setup<G, POOL>(lds, G * RB, cap, nch, lane, spill_buf, div, (size_t)div * div, (size_t)x * div + z, &counters[4], active);
+    const Env<G, POOL> E = env_setup<G, POOL>(lds, G * RB, cap, nch, lane, spill_buf, div, (size_t)div * div, (size_t)x * div + z, &counters[4]);
 
     if (g < G) {
         const int klo = cnt * g / G, khi = cnt * (g + 1) / G;
@@ -629,12 +627,11 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restric
     extern __shared__ unsigned lds[];
     const int y = blockIdx.x / nchunk, c = blockIdx.x % nchunk;
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool active = c * 64 + lane < div;
-    const int z = active ? c * 64 + lane : div - 1;
+    const int z = min(c * 64 + lane, div - 1);   // lanes beyond the row's end shadow its last voxel: same work, same stores
     const int np = (int)counters[2];
     const size_t xs = (size_t)div * div;                  // elements between consecutive x
     const int rowoff = y * div + z;
-    const Env<G, POOL> E = env_setup<G, POOL>(lds, G * RB, cap, nch, lane, spill_buf, div, xs, (size_t)rowoff, &counters[5], active);
+    const Env<G, POOL> E = env_setup<G, POOL>(lds, G * RB, cap, nch, lane, spill_buf, div, xs, (size_t)rowoff, &counters[5]);
 
     if (g < G) {
         const int klo = np * g / G, khi = np * (g + 1) / G;
