@@ -595,11 +595,15 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_zy(const RowRec* __res
                 const int u = bcast(cur.w, j);
                 const u64 own = ((u64)hi << 32) | lo;
                 const int below = (int)(ba & 0xffff) - 1, above = (int)(ba >> 16);
-                const u64 md = own & (~0ull >> (63 - zl));
-                const u64 mu = own >> zl;
-                const int down = md ? zl - (63 - __clzll(md)) : (below >= 0 ? z - below : BIGD);
-                const int up = mu ? (__ffsll((long long)mu) - 1) : (above != 0xffff ? above - z : BIGD);
-                const int gd = min(down, up);
+                // nearest voxel of the row outside this chunk (the record is the same for all lanes: scalar work)
+                const int far_below = below >= 0 ? below : -BIGD, far_above = above != 0xffff ? above : BIGD;
+                int gd = min(z - far_below, far_above - z);
+                if (own != 0) {   // wave-uniform: most rows of a plane have no voxel inside a given chunk
+                    const u64 md = own & (~0ull >> (63 - zl));
+                    const u64 mu = own >> zl;
+                    if (md) gd = min(gd, zl - (63 - __clzll(md)));   // a voxel inside the chunk is nearer than any beyond it on its side
+                    if (mu) gd = min(gd, __ffsll((long long)mu) - 1);
+                }
                 env_add(E, g, e, u, __mul24(gd, gd), div);
             }
         }
