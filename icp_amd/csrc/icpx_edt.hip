@@ -19,6 +19,9 @@
 #include <hip/hip_ext.h>
 
 #include "icpx_ctx.h"
+
+#include <cstdio>
+#include <cstdlib>
 #include "icpx_edt_dev.h"
 
 #include <algorithm>
@@ -730,6 +733,9 @@ static void edt_adapt(icpx_ctx* ctx, u64 deepest_zy, u64 deepest_x) {
         fits = fits && f;
     }
     if (fits) ctx->edt_overflowed = false;
+    if (getenv("ICPX_EDT_VERBOSE"))
+        fprintf(stderr, "icpx edt: div %u deepest stack zy %llu x %llu -> levels,chunks zy %d,%d x %d,%d\n", ctx->div, (unsigned long long)deepest_zy,
+                (unsigned long long)deepest_x, ctx->edt_zy.cap, ctx->edt_zy.chunks, ctx->edt_x.cap, ctx->edt_x.chunks);
 }
 
 // Launch on the stream; with ev != NULL the dispatch carries the start / stop events of its stage, which
