@@ -7,7 +7,8 @@
 //
 // Pipeline (all on one stream):
 //   splat    points -> occupancy bits (one bit per voxel, 64-bit words along z)      src/testLDT.cpp:74-88
-//   census   per plane x: records of the rows y that hold any occupied voxel; list of non-empty planes
+//   census   per plane x: records of the rows y that hold any occupied voxel (the list of non-empty planes is
+//            put together by one extra workgroup of pass zy)
 //   pass zy  per plane x and 64-wide z chunk (one lane per z): distance along z from the bit row
 //            (:91-109), then the lower envelope along y (:123-157); rows without voxels never win the
 //            envelope, so only the plane's non-empty rows are scanned
@@ -19,12 +20,10 @@
 #include <hip/hip_ext.h>
 
 #include "icpx_ctx.h"
-
-#include <cstdio>
-#include <cstdlib>
 #include "icpx_edt_dev.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 typedef unsigned long long u64;
@@ -177,8 +176,9 @@ __device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70)
 // lane (Meijster's scan, src/testLDT.cpp:123-157 / :172-206). A serial scan over all sites of a row is one
 // long dependent chain and a div^3 grid only has div^2 rows, too few waves to keep the SIMDs busy, so the
 // scan is split: wave g of a workgroup builds the envelope stack of the g-th part of the row's sites (the
-// same 64 rows in every wave), then, after a barrier, wave g evaluates the g-th part of the positions
-// against all G stacks and takes the minimum. The stacks are never merged.
+// same 64 rows in every wave), then, after a barrier, every wave of the workgroup (the G that scanned and,
+// in the default shape, G more that waited for them) evaluates its part of the positions against the stacks
+// that can win there and takes the minimum. The stacks are never merged.
 //
 // A stack entry is {site s, a = s^2 + value} in one dword (s << 22 | a; a <= 3 (div - 1)^2 < 2^22 because
 // div <= 1023) and, in a halfword, twice the first position t the entry owns among the entries of its own
@@ -190,7 +190,9 @@ __device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70)
 //   beyond, or pool exhausted   global spill buffer [level - cap][group][row] of 8-byte entries, allocated
 //                               only after a build reported through the overflow counter that it is needed
 // Most stacks are a handful of levels deep and a few are several times deeper, so a small private part
-// plus the shared pool holds what a fixed split of the same LDS could not.
+// plus the shared pool holds what a fixed split of the same LDS could not. A stack never holds more entries
+// than its group has sites; when that fits three workgroups' worth of LDS per CU the host drops the pool
+// (POOL = false: every level private, a sentinel row below each stack, the site step hand-written).
 constexpr int ENV_VB = 22;
 constexpr unsigned ENV_VMASK = (1u << ENV_VB) - 1;
 constexpr int ENV_CHUNK = 8;        // levels per pool chunk
