@@ -94,6 +94,7 @@ extern "C" void icpx_destroy(icpx_ctx* ctx) {
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->bnb_pin) (void)hipHostFree(ctx->bnb_pin);
+    if (ctx->pin_sums) (void)hipHostFree(ctx->pin_sums);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
