@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--nn-points", type=int, default=1_000_000)
     ap.add_argument("--no-goicp", action="store_true", help="skip the Go-ICP bunny-270 extra")
     ap.add_argument("--goicp-width", type=int, default=8, help="translation parents popped per inner search and step")
+    ap.add_argument("--goicp-lookahead", type=int, default=4, help="queued translation cubes whose children are evaluated ahead of time (reference order)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo for CPU-side rehearsal)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -237,7 +238,7 @@ def main():
             # whose lower bound is within the threshold, so the order decides where it stops); the wider frontier is the
             # throughput form and may stop elsewhere.
             for width in sorted({1, args.goicp_width}):
-                go.options(batched=True, frontier_width=width)
+                go.options(batched=True, frontier_width=width, lookahead=args.goicp_lookahead if width == 1 else 0)
                 barrier(); t0 = time.perf_counter()
                 gr = go.registration()
                 barrier()
@@ -246,7 +247,8 @@ def main():
                     "time_to_optimum_s": el, "optimal_sse": float(gr["optError"]), "lower_bound": float(gr["lb"]),
                     "epsilon": float(gr["sseThresh"]), "initial_sse": float(gr["initError"]), "icp_sse": float(gr["icpError"]),
                     "rotation_cubes": gr["rot_pops"], "bound_evaluations": gr["inner_evals"], "launches": gr["launches"],
-                    "points": int(gd.shape[0]), "frontier_width": width}
+                    "points": int(gd.shape[0]), "frontier_width": width,
+                    "lookahead": args.goicp_lookahead if width == 1 else 0}
             del go
 
     cpu = None

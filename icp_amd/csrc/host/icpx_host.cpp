@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <queue>
+#include <unordered_map>
 
 namespace icp {
 
@@ -530,56 +531,124 @@ void GoIcp::eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub
 }
 
 // One inner (translation) search: the state of GoIcp::innerBnB between two bound evaluations.
+namespace {
+struct TransQueue : std::priority_queue<TransNode> {
+    const std::vector<TransNode>& heap() const { return c; }   // the binary heap itself, for looking ahead without popping
+};
+struct CubeKey {
+    uint32_t k[4];
+    bool operator==(const CubeKey& o) const { return std::memcmp(k, o.k, sizeof k) == 0; }
+};
+struct CubeKeyHash {
+    size_t operator()(const CubeKey& c) const {
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+        for (uint32_t v : c.k) h = (h ^ v) * 0x100000001b3ull;
+        return (size_t)h;
+    }
+};
+CubeKey key_of(const TransNode& n) {
+    CubeKey c;
+    std::memcpy(&c.k[0], &n.x, 4); std::memcpy(&c.k[1], &n.y, 4); std::memcpy(&c.k[2], &n.z, 4); std::memcpy(&c.k[3], &n.w, 4);
+    return c;
+}
+struct ChildBounds { float ub[8], lb[8]; };
+}  // namespace
+
 struct GoIcp::Search {
     float R[9];
     int level;                 // -1: upper-bound form
-    std::priority_queue<TransNode> que;
+    TransQueue que;
     float optErrorT;
     TransNode best;
     bool have_best = false, done = false;
-    std::vector<TransNode> pending;   // children awaiting their bounds, in evaluation order
+    std::vector<TransNode> pending;   // parents whose 8 children are in the batch, in evaluation order
+    std::unordered_map<CubeKey, ChildBounds, CubeKeyHash> ahead;   // bounds of the children of cubes not popped yet
 };
+
+// The eight children of a translation cube in the reference's order (src/GoIcp.cpp:391-401).
+static TransNode child_of(const TransNode& parent, int j) {
+    TransNode node;
+    node.w = (float)(parent.w / 2.0);
+    node.x = parent.x + (j & 1) * node.w;
+    node.y = parent.y + (j >> 1 & 1) * node.w;
+    node.z = parent.z + (j >> 2 & 1) * node.w;
+    node.lb = node.ub = 0;
+    return node;
+}
 
 void GoIcp::run_searches(std::vector<Search>& ss) {
     std::vector<icpx_bnb_item> items;
     std::vector<float> ub, lb;
     const int width = std::max(1, frontier_width);
+    const int ahead = width == 1 ? std::max(0, lookahead) : 0;
+    std::vector<size_t> cand;    // look-ahead: heap positions still to visit
+    // Takes the children's bounds of one popped parent in the reference's order (src/GoIcp.cpp:403-452).
+    auto take = [&](Search& s, const TransNode& parent, const float* u8, const float* l8) {
+        for (int j = 0; j < 8 && !s.done; j++) {
+            TransNode node = child_of(parent, j);
+            const float u = u8[j], l = l8[j];
+            if (u < s.optErrorT) { s.optErrorT = u; s.best = node; s.have_best = true; }
+            if (l >= s.optErrorT) continue;
+            node.lb = l; node.ub = u;
+            if (s.optErrorT - node.lb < sseThresh) { s.done = true; continue; }
+            s.que.push(node);
+        }
+    };
     for (;;) {
         items.clear();
         for (Search& s : ss) {
             s.pending.clear();
             if (s.done) continue;
+            // parents whose children were evaluated ahead of time need no launch
+            while (ahead && !s.done && !s.que.empty()) {
+                auto it = s.ahead.find(key_of(s.que.top()));
+                if (it == s.ahead.end()) break;
+                const TransNode parent = s.que.top(); s.que.pop();
+                const ChildBounds cb = it->second;
+                s.ahead.erase(it);
+                take(s, parent, cb.ub, cb.lb);
+            }
+            if (s.done) continue;
             if (s.que.empty()) { s.done = true; continue; }
             for (int k = 0; k < width && !s.que.empty(); k++) {
-                const TransNode parent = s.que.top(); s.que.pop();
-                TransNode node;
-                node.w = (float)(parent.w / 2.0);
+                s.pending.push_back(s.que.top()); s.que.pop();
+            }
+            if (ahead) {
+                // the `ahead` best cubes left in the heap, found from its root without disturbing it
+                const std::vector<TransNode>& h = s.que.heap();
+                cand.clear();
+                if (!h.empty()) cand.push_back(0);
+                for (int k = 0; k < ahead && !cand.empty(); k++) {
+                    size_t bi = 0;
+                    for (size_t c = 1; c < cand.size(); c++) if (h[cand[c]].lb < h[cand[bi]].lb) bi = c;
+                    const size_t i = cand[bi];
+                    cand[bi] = cand.back(); cand.pop_back();
+                    if (2 * i + 1 < h.size()) cand.push_back(2 * i + 1);
+                    if (2 * i + 2 < h.size()) cand.push_back(2 * i + 2);
+                    if (!s.ahead.count(key_of(h[i]))) s.pending.push_back(h[i]);
+                }
+            }
+            for (const TransNode& parent : s.pending)
                 for (int j = 0; j < 8; j++) {
-                    node.x = parent.x + (j & 1) * node.w;
-                    node.y = parent.y + (j >> 1 & 1) * node.w;
-                    node.z = parent.z + (j >> 2 & 1) * node.w;
-                    node.lb = node.ub = 0;
-                    s.pending.push_back(node);
+                    const TransNode node = child_of(parent, j);
                     icpx_bnb_item it;
                     std::memcpy(it.R, s.R, sizeof it.R);
                     it.x = node.x; it.y = node.y; it.z = node.z; it.w = node.w; it.level = s.level;
                     items.push_back(it);
                 }
-            }
         }
         if (items.empty()) break;
         eval_items(items, ub, lb);
         size_t pos = 0;
         for (Search& s : ss) {
-            for (size_t k = 0; k < s.pending.size(); k++, pos++) {
-                if (s.done) continue;           // an earlier child of this batch ended the search
-                TransNode node = s.pending[k];
-                const float u = ub[pos], l = lb[pos];
-                if (u < s.optErrorT) { s.optErrorT = u; s.best = node; s.have_best = true; }
-                if (l >= s.optErrorT) continue;
-                node.lb = l; node.ub = u;
-                if (s.optErrorT - node.lb < sseThresh) { s.done = true; continue; }
-                s.que.push(node);
+            const size_t popped = std::min<size_t>(s.pending.size(), (size_t)width);
+            for (size_t k = 0; k < s.pending.size(); k++, pos += 8) {
+                if (k < popped) { if (!s.done) take(s, s.pending[k], &ub[pos], &lb[pos]); }   // an earlier parent of this batch may have ended the search
+                else {
+                    ChildBounds cb;
+                    std::memcpy(cb.ub, &ub[pos], sizeof cb.ub); std::memcpy(cb.lb, &lb[pos], sizeof cb.lb);
+                    s.ahead.emplace(key_of(s.pending[k]), cb);
+                }
             }
         }
     }
@@ -939,10 +1008,10 @@ void* icpxh_goicp_new(int device, const float* model, size_t nm, const float* da
     return h;
 }
 void icpxh_goicp_free(void* p) { delete (HGo*)p; }
-int icpxh_goicp_options(void* p, int run_bnb, int batched, int parity_sums, int frontier_width, long long max_rot_pops) {
+int icpxh_goicp_options(void* p, int run_bnb, int batched, int parity_sums, int frontier_width, long long max_rot_pops, int lookahead) {
     HGo* h = (HGo*)p;
     h->go->run_bnb = run_bnb != 0; h->go->batched = batched != 0; h->go->parity_sums = parity_sums != 0;
-    h->go->frontier_width = frontier_width; h->go->max_rot_pops = max_rot_pops;
+    h->go->frontier_width = frontier_width; h->go->max_rot_pops = max_rot_pops; h->go->lookahead = lookahead;
     return 0;
 }
 int icpxh_goicp_set_collective(void* p, int rank, int world, void (*allreduce)(double*, int)) {

@@ -40,7 +40,7 @@ def _lib():
         lib.icpxh_icp3d_free.argtypes = [C.c_void_p]; lib.icpxh_icp3d_free.restype = None
         lib.icpxh_icp3d_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_int,
                                         C.c_double, C.c_void_p, C.c_void_p]
-        lib.icpxh_goicp_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong]
+        lib.icpxh_goicp_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int]
         lib.icpxh_goicp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
         lib.icpxh_goicp_registration.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.icpxh_goicp_inner.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
@@ -244,8 +244,8 @@ class GoIcp:
             self._cb = make_allreduce(allreduce)
             _ck(_lib().icpxh_goicp_set_collective(self._h, rank, world, self._cb))
 
-    def options(self, run_bnb=True, batched=True, parity_sums=False, frontier_width=1, max_rot_pops=0):
-        _ck(_lib().icpxh_goicp_options(self._h, int(run_bnb), int(batched), int(parity_sums), frontier_width, max_rot_pops))
+    def options(self, run_bnb=True, batched=True, parity_sums=False, frontier_width=1, max_rot_pops=0, lookahead=4):
+        _ck(_lib().icpxh_goicp_options(self._h, int(run_bnb), int(batched), int(parity_sums), frontier_width, max_rot_pops, lookahead))
         return self
 
     def registration(self, want_points=False):

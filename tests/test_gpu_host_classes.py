@@ -220,3 +220,10 @@ def test_goicp_bunny270_against_oracle_golden(bunny000, bun270):
         assert float(r["initError"]) == gold["initError"]
         assert abs(float(r["icpError"]) - gold["icpError"]) <= 1e-6 * gold["icpError"]
         assert float(r["optError"]) - r["lb"] < r["sseThresh"]          # certificate
+    # bounds evaluated ahead of time change neither a decision nor the result of the reference's order: the same
+    # rotation cubes, bit-identical optimum and lower bound, in fewer launches
+    r1 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=0).registration()
+    r4 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=4).registration()
+    assert r4["rot_pops"] == r1["rot_pops"] and float(r4["optError"]) == float(r1["optError"]) and r4["lb"] == r1["lb"]
+    assert np.array_equal(r4["optMat"], r1["optMat"])
+    assert r4["launches"] < r1["launches"]
