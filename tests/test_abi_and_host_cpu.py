@@ -172,8 +172,12 @@ def test_sharded_sums_allreduce_gloo_world2(tmp_path):
     transform on every rank. Runs on CPU with the gloo backend; the per-slice sums come from the oracle."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", OMP_NUM_THREADS="2")
+    import socket
+    with socket.socket() as sock:      # a port nobody holds right now (a fixed one may still be in TIME_WAIT from an earlier run)
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29577", str(script), ROOT], env=env, capture_output=True, text=True, timeout=240)
+                        "--master-port", port, str(script), ROOT], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
