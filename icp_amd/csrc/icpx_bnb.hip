@@ -165,6 +165,10 @@ extern "C" int icpx_goicp_read_maxrotdist(icpx_ctx* ctx, float* out) {
 
 // Grow-only pinned host buffer: copies through it are truly asynchronous and take one DMA each, where a
 // pageable source or destination is staged by the runtime in several steps.
+#ifndef ICPX_BNB_SLICES
+#define ICPX_BNB_SLICES 16
+#endif
+
 static int bnb_pin_reserve(icpx_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->bnb_pin_cap) return ICPX_OK;
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -183,9 +187,9 @@ static int bnb_enqueue(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems,
     for (size_t i = 0; i < nitems; i++)
         if (items[i].level >= ICPX_MAXROTLEVEL) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval: item %zu has level %d >= %d", i, items[i].level, ICPX_MAXROTLEVEL);
     const size_t n = ctx->nd;
-    int nsplit = (int)((4 * (size_t)ctx->num_cus + nitems - 1) / nitems);
-    const int maxsplit = (int)((n + 1023) / 1024);
-    if (nsplit > maxsplit) nsplit = maxsplit;
+    // Slices per item: a function of the cloud alone, never of the batch, so that the bounds of a cube are the
+    // same bits whichever cubes it shares a launch with (the partial sums are added in slice order).
+    int nsplit = (int)std::min<size_t>((n + 1023) / 1024, ICPX_BNB_SLICES);
     if (nsplit < 1) nsplit = 1;
     ICPX_TRY(icpx_reserve(ctx, ctx->bnb_items, nitems * sizeof(icpx_bnb_item)));
     ICPX_TRY(icpx_reserve(ctx, ctx->bnb_partials, nitems * nsplit * 2 * sizeof(double)));
