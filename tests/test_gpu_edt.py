@@ -34,6 +34,18 @@ def test_edt_bunny_300_and_lookup(gpu_ctx, oracle, bunny045, bunny000):
     got = gpu_ctx.edt_lookup(q)
     want = oracle.ldt_lookup(sq, mn, cell, q)
     assert np.array_equal(got, want)
+    # coordinates on and a few float steps around every cell boundary, where a cheaper division would pick the wrong cell
+    k = np.arange(0, 301, dtype=np.float32)
+    edge = (np.float32(mn[0]) + k * np.float32(cell)).astype(np.float32)
+    xs = np.concatenate([np.nextafter(edge, np.float32(np.inf) * s, dtype=np.float32) if n else edge
+                         for n, s in ((0, 1), (1, 1), (1, -1))])
+    xs = np.concatenate([xs, np.nextafter(np.nextafter(edge, np.float32(np.inf)), np.float32(np.inf)),
+                         np.nextafter(np.nextafter(edge, -np.float32(np.inf)), -np.float32(np.inf))]).astype(np.float32)
+    for axis in range(3):
+        qe = np.tile(bunny000[:1].astype(np.float32), (xs.size, 1))
+        qe[:, axis] = xs - np.float32(mn[0]) + np.float32(mn[axis])
+        qe = np.ascontiguousarray(qe)
+        assert np.array_equal(gpu_ctx.edt_lookup(qe), oracle.ldt_lookup(sq, mn, cell, qe))
 
 
 def test_edt_dense_random_and_spill(gpu_ctx, oracle):
