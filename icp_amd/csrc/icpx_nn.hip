@@ -104,7 +104,7 @@ struct Best {               // the single nearest
 };
 
 template <int K>
-struct BestK {              // the K nearest, ascending; unused slots hold (INFINITY, 0x7fffffff)
+struct BestK {              // the K nearest, ascending; unused slots hold (INFINITY, 0x7fffffff); a point is offered at most once
     double d2[K];
     int idx[K];
     __device__ __forceinline__ void init() {
@@ -114,11 +114,6 @@ struct BestK {              // the K nearest, ascending; unused slots hold (INFI
     __device__ __forceinline__ double bound() const { return d2[K - 1]; }
     __device__ __forceinline__ void offer(double d, int id) {
         if (!(d < d2[K - 1] || (d == d2[K - 1] && id < idx[K - 1]))) return;
-        // the pyramid walk revisits the cells of the 3x3x3 block: a point that is already kept must not enter twice
-        bool kept = false;
-#pragma unroll
-        for (int k = 0; k < K; k++) kept |= idx[k] == id;
-        if (kept) return;
         // one pass of insertion from the back: shift the larger entries up, drop the candidate in its place
 #pragma unroll
         for (int k = K - 1; k >= 0; k--) {
@@ -154,8 +149,6 @@ __device__ __forceinline__ double box_lb2(double qx, double qy, double qz, doubl
            axis_gap2(qz, oz + k * side, oz + (k + 1) * side, margin);
 }
 
-constexpr int NN_LEVELS = MAXLEV + 1;   // per-thread walk state: one word per pyramid level
-
 // Children of a node in visiting order for a query whose nearest octant is `near`: bit t of the result is
 // child near ^ j(t), with j = 0, 1, 2, 4, 3, 5, 6, 7 (by number of axes in which the child lies on the far
 // side). XOR of the child number is a bit permutation of the mask: swap neighbours, pairs, halves.
@@ -167,99 +160,14 @@ __device__ __forceinline__ unsigned pyr_visit_order(unsigned m, int near) {
     return m ^ (x << 3) ^ (x << 4);
 }
 
-// Exact nearest neighbour. Fast path: the query's own cell and the 26 around it; it is final when the
-// best distance found is smaller than the distance to everything outside that 3x3x3 block. Otherwise
-// (query far from the cloud, or a large empty gap) a depth-first walk down the occupancy pyramid,
-// nearer children first, skipping empty subtrees (one mask byte per node tells which children hold points)
-// and those whose box is farther than the best so far. The walk keeps one word per level in LDS at
-// `state[level * sstride]`; `loff` are the per-level mask offsets staged in LDS.
-// `b` comes in initialised: empty (init()), or holding candidates that are real target points, e.g. the
-// correspondence of the previous ICP iteration, whose distance then prunes the search from the start; the
-// result does not depend on them (a candidate met again is not entered twice, equal distances still go to
-// the lower index because cells are only skipped when their bound is strictly larger).
-template <class R>
-__device__ R nn_search_t(const GridView& g, double qx, double qy, double qz, unsigned* state, int sstride, const unsigned* loff, R b) {
-    const int cx = cell_coord((float)qx, g.minx, g.inv, g.dx), cy = cell_coord((float)qy, g.miny, g.inv, g.dy),
-              cz = cell_coord((float)qz, g.minz, g.inv, g.dz);
-    const double h = (double)g.h;
-    // Cell membership of the target points was decided in float arithmetic: a point can sit up to a few
-    // float ulps outside the box of its cell. The margin makes every lower bound conservative.
-    const double margin = 1e-3 * h + 1e-6 * (fabs(qx) + fabs(qy) + fabs(qz));
-    const double ox = (double)g.minx, oy = (double)g.miny, oz = (double)g.minz;
-    scan_cell(g, (cx * g.dy + cy) * g.dz + cz, qx, qy, qz, b);
-    const int i0 = max(cx - 1, 0), i1 = min(cx + 1, g.dx - 1);
-    const int j0 = max(cy - 1, 0), j1 = min(cy + 1, g.dy - 1);
-    const int k0 = max(cz - 1, 0), k1 = min(cz + 1, g.dz - 1);
-    for (int i = i0; i <= i1; i++) {
-        const double gx = axis_gap2(qx, ox + i * h, ox + (i + 1) * h, margin);
-        if (gx > b.bound()) continue;
-        for (int j = j0; j <= j1; j++) {
-            const double gxy = gx + axis_gap2(qy, oy + j * h, oy + (j + 1) * h, margin);
-            if (gxy > b.bound()) continue;
-            const int row = (i * g.dy + j) * g.dz;
-            for (int k = k0; k <= k1; k++) {
-                if (i == cx && j == cy && k == cz) continue;
-                if (gxy + axis_gap2(qz, oz + k * h, oz + (k + 1) * h, margin) > b.bound()) continue;
-                scan_cell(g, row + k, qx, qy, qz, b);
-            }
-        }
-    }
-    // Everything outside the 3x3x3 block lies beyond one of its six faces (where the grid continues).
-    double outside = INFINITY;
-    if (cx + 2 <= g.dx - 1) { const double t = fmax(ox + (cx + 2) * h - qx - margin, 0.0); outside = fmin(outside, t * t); }
-    if (cx - 2 >= 0)        { const double t = fmax(qx - (ox + (cx - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
-    if (cy + 2 <= g.dy - 1) { const double t = fmax(oy + (cy + 2) * h - qy - margin, 0.0); outside = fmin(outside, t * t); }
-    if (cy - 2 >= 0)        { const double t = fmax(qy - (oy + (cy - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
-    if (cz + 2 <= g.dz - 1) { const double t = fmax(oz + (cz + 2) * h - qz - margin, 0.0); outside = fmin(outside, t * t); }
-    if (cz - 2 >= 0)        { const double t = fmax(qz - (oz + (cz - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
-    if (outside > b.bound()) return b;
-
-    // Pyramid walk from the root node (level nlev - 1, a single node). The node being expanded is (l; ni, nj,
-    // nk); `vis` holds its children that hold points and are not handled yet, bit t = the t-th child in
-    // visiting order (the octant the query lies in first, then the three that differ in one axis, ...).
-    // state[l] keeps {vis, near octant} of the ancestor at level l while the walk is below it; coordinates
-    // of an ancestor are those of the node shifted right.
-    const int top = g.nlev - 1;
-    if (top == 0) return b;   // a single cell was covered by the block above
-    int l = top, ni = 0, nj = 0, nk = 0, near = 0;
-    unsigned vis = 0;
-    bool enter = true;
-    for (;;) {
-        if (enter) {          // (l; ni, nj, nk) has just become the node to expand
-            const int ndy = lev_dim(g.dy, l), ndz = lev_dim(g.dz, l);
-            const unsigned m = g.flags[loff[l] + ((size_t)ni * ndy + nj) * ndz + nk];
-            const double half = h * (double)(1 << (l - 1));
-            near = (qx >= ox + (2 * ni + 1) * half ? 4 : 0) | (qy >= oy + (2 * nj + 1) * half ? 2 : 0) | (qz >= oz + (2 * nk + 1) * half ? 1 : 0);
-            vis = pyr_visit_order(m, near);
-            enter = false;
-        }
-        if (vis == 0) {       // done with this node: back to its parent
-            if (l == top) break;
-            l++; ni >>= 1; nj >>= 1; nk >>= 1;
-            const unsigned w = state[l * sstride];
-            vis = w & 0xffu; near = (int)(w >> 8);
-            continue;
-        }
-        const int t = __ffs((int)vis) - 1;
-        vis &= vis - 1;
-        const int oct = near ^ (t == 3 ? 4 : t == 4 ? 3 : t);
-        const int ci = 2 * ni + (oct >> 2), cj = 2 * nj + ((oct >> 1) & 1), ck = 2 * nk + (oct & 1);
-        const int cl = l - 1;
-        if (box_lb2(qx, qy, qz, ox, oy, oz, h * (double)(1 << cl), ci, cj, ck, margin) > b.bound()) continue;
-        if (cl == 0) {
-            scan_cell(g, (ci * g.dy + cj) * g.dz + ck, qx, qy, qz, b);
-        } else {
-            state[l * sstride] = vis | ((unsigned)near << 8);
-            l = cl; ni = ci; nj = cj; nk = ck;
-            enter = true;
-        }
-    }
-    return b;
-}
-
-// ---- the same search by eight lanes per query -----------------------------------------------------------
-// One lane per query leaves a long chain of dependent loads (mask, cell range, points, next mask ...) and,
-// for clouds of some ten thousand points, fewer waves than the GPU has SIMDs. Here the eight lanes of an
+// ---- the search: eight lanes per query --------------------------------------------------------------------
+// Exact nearest neighbour(s). First the query's own cell and the 26 around it; that is final when the bound
+// (the distance of the nearest, or k-th nearest, found) is smaller than the distance to everything outside that
+// 3x3x3 block. Otherwise (query far from the cloud, or a large empty gap) a walk down the occupancy pyramid,
+// nearer children first, skipping empty subtrees (one mask byte per node tells which children hold points) and
+// those whose box is farther than the bound.
+// One lane per query would leave a long chain of dependent loads (mask, cell range, points, next mask ...) and,
+// for clouds of some ten thousand points, fewer waves than the GPU has SIMDs. So the eight lanes of an
 // aligned group ("octet") share one query: the 27 cells of the first block are dealt out over the lanes,
 // and in the walk lane c owns child c of the node being expanded, so the eight bounds are computed, and at
 // the lowest level the up to eight cells scanned, side by side. All lanes of an octet hold the same walk
@@ -276,12 +184,60 @@ __device__ __forceinline__ Best octet_min(Best b) {
     return b;
 }
 
+__device__ __forceinline__ void octet_merge(Best& b) { b = octet_min(b); }
+
+// k nearest for an octet: `g` is the octet's k best so far (the same in all eight lanes, it gives the bound),
+// `l` what this lane has found since the last merge. A point is met by one lane only (every cell is scanned once),
+// so the lists are disjoint and the merge is a k-round selection: every round takes the smaller of g's head and
+// the best head among the lanes' lists (octet_min) and removes it from where it came.
+template <int K>
+struct OctK {
+    BestK<K> g, l;
+    __device__ __forceinline__ void init() { g.init(); l.init(); }
+    __device__ __forceinline__ double bound() const { return g.d2[K - 1]; }
+    __device__ __forceinline__ void offer(double d, int id) {
+        if (!(d < g.d2[K - 1] || (d == g.d2[K - 1] && id < g.idx[K - 1]))) return;
+        l.offer(d, id);
+    }
+};
+
+template <int K>
+__device__ __forceinline__ void octet_merge(OctK<K>& b) {
+    // nothing new in any lane: g stands
+    if (((__ballot(b.l.idx[0] != 0x7fffffff) >> (threadIdx.x & 56)) & 0xffull) == 0) return;
+    BestK<K> out;
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        Best head;
+        head.d2 = b.l.d2[0]; head.idx = b.l.idx[0];
+        const Best m = octet_min(head);
+        const bool from_g = b.g.d2[0] < m.d2 || (b.g.d2[0] == m.d2 && b.g.idx[0] <= m.idx);
+        out.d2[r] = from_g ? b.g.d2[0] : m.d2;
+        out.idx[r] = from_g ? b.g.idx[0] : m.idx;
+        const bool mine = !from_g && b.l.idx[0] == m.idx;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool last = k == K - 1;
+            const double gd = last ? (double)INFINITY : b.g.d2[last ? k : k + 1], ld = last ? (double)INFINITY : b.l.d2[last ? k : k + 1];
+            const int gi = last ? 0x7fffffff : b.g.idx[last ? k : k + 1], li = last ? 0x7fffffff : b.l.idx[last ? k : k + 1];
+            b.g.d2[k] = from_g ? gd : b.g.d2[k]; b.g.idx[k] = from_g ? gi : b.g.idx[k];
+            b.l.d2[k] = mine ? ld : b.l.d2[k]; b.l.idx[k] = mine ? li : b.l.idx[k];
+        }
+    }
+    b.g = out;
+    b.l.init();
+}
+
 constexpr int NN_OCTETS = 32;   // octets per 256-thread block
 constexpr int NN_STACK = 72;    // 1 + 7 entries for each of the (at most ten) levels above the cells, rounded up
 
 // `snode`, `slb`: the walk's stack in LDS, NN_STACK entries per octet, entry k of octet o at [k * NN_OCTETS + o];
-// `b`: initial candidate, the same in all lanes.
-__device__ Best nn_search8(const GridView& g, double qx, double qy, double qz, unsigned* snode, double* slb, const unsigned* loff, Best b) {
+// `b`: the result so far (Best or OctK<K>), initialised, the same in all lanes: empty, or holding candidates
+// that are real target points, e.g. the correspondence of the previous ICP iteration, whose distance then prunes
+// the search from the start; the result does not depend on them (equal distances still go to the lower index
+// because cells are only skipped when their bound is strictly larger).
+template <class R>
+__device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsigned* snode, double* slb, const unsigned* loff, R b) {
     const int c = (int)(threadIdx.x & 7);
     const int cx = cell_coord((float)qx, g.minx, g.inv, g.dx), cy = cell_coord((float)qy, g.miny, g.inv, g.dy),
               cz = cell_coord((float)qz, g.minz, g.inv, g.dz);
@@ -297,7 +253,7 @@ __device__ Best nn_search8(const GridView& g, double qx, double qy, double qz, u
             !(box_lb2(qx, qy, qz, ox, oy, oz, h, i, j, k, margin) > b.bound()))
             scan_cell(g, (i * g.dy + j) * g.dz + k, qx, qy, qz, b);
     }
-    b = octet_min(b);
+    octet_merge(b);
     double outside = INFINITY;
     if (cx + 2 <= g.dx - 1) { const double t = fmax(ox + (cx + 2) * h - qx - margin, 0.0); outside = fmin(outside, t * t); }
     if (cx - 2 >= 0)        { const double t = fmax(qx - (ox + (cx - 1) * h) - margin, 0.0); outside = fmin(outside, t * t); }
@@ -335,7 +291,7 @@ __device__ Best nn_search8(const GridView& g, double qx, double qy, double qz, u
             // the children are cells: every lane scans its own (those of the first block are done already)
             const bool seen = ci >= cx - 1 && ci <= cx + 1 && cj >= cy - 1 && cj <= cy + 1 && ck >= cz - 1 && ck <= cz + 1;
             if (ok && !seen) scan_cell(g, (ci * g.dy + cj) * g.dz + ck, qx, qy, qz, b);
-            b = octet_min(b);
+            octet_merge(b);
             continue;
         }
         const unsigned cand = (unsigned)(__ballot(ok) >> (threadIdx.x & 56)) & 0xffu;
@@ -378,20 +334,22 @@ __device__ __forceinline__ Best best_seed(const int* __restrict__ seed, size_t i
 template <int K>
 __global__ __launch_bounds__(256) void k_knn(GridView g, const double* __restrict__ q, size_t n, int kout, int* __restrict__ idx,
                                              double* __restrict__ d2) {
-    __shared__ unsigned stk[NN_LEVELS * 256];
+    __shared__ unsigned snode[NN_STACK * NN_OCTETS];
+    __shared__ double slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;   // eight lanes per query
     if (i >= n) return;
-    BestK<K> b0;
+    OctK<K> b0;
     b0.init();
-    const BestK<K> b = nn_search_t<BestK<K>>(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], stk + threadIdx.x, 256, s_loff, b0);
+    const OctK<K> b = nn_search8(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], snode, slb, s_loff, b0);
+    if ((threadIdx.x & 7) != 0) return;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         if (k < kout) {
-            if (idx) idx[i * kout + k] = b.idx[k] == 0x7fffffff ? -1 : b.idx[k];
-            if (d2) d2[i * kout + k] = b.d2[k];
+            if (idx) idx[i * kout + k] = b.g.idx[k] == 0x7fffffff ? -1 : b.g.idx[k];
+            if (d2) d2[i * kout + k] = b.g.d2[k];
         }
     }
 }
@@ -707,7 +665,7 @@ extern "C" int icpx_knn(icpx_ctx* ctx, const double* q_xyz, size_t n, int where,
         if (idx) { ICPX_TRY(icpx_reserve(ctx, ctx->scratch_idx, n * k * sizeof(int))); didx = ctx->scratch_idx.as<int>(); }
         if (d2) { ICPX_TRY(icpx_reserve(ctx, ctx->scratch_d2, n * k * sizeof(double))); dd2 = ctx->scratch_d2.as<double>(); }
     }
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const dim3 grid((unsigned)((n + 31) / 32)), block(256);   // eight lanes per query
     if (k == 1) hipLaunchKernelGGL(k_knn<1>, grid, block, 0, ctx->stream, view_of(ctx), dq, n, k, didx, dd2);
     else if (k == 2) hipLaunchKernelGGL(k_knn<2>, grid, block, 0, ctx->stream, view_of(ctx), dq, n, k, didx, dd2);
     else if (k <= 4) hipLaunchKernelGGL(k_knn<4>, grid, block, 0, ctx->stream, view_of(ctx), dq, n, k, didx, dd2);
