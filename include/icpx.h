@@ -101,7 +101,8 @@ int icpx_set_source(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_byt
  *   sums[0..2] = sum p, sums[3..5] = sum q, sums[6..14] = sum p q^T, sums[15] = sum |p - q|^2.
  * The caller forms the means, H = (sum p q^T - pbar (sum q)^T) / n, and runs the 3x3 SVD on the host.
  * sums: 16 doubles of host memory. idx_opt: NULL, or n int32 (memory kind `idx_where`) receiving the
- * correspondences in the caller's point order. */
+ * correspondences in the caller's point order. The context remembers every source point's correspondence and
+ * starts the next pass's search from it; that only prunes the search, the pairs are those of a search from scratch. */
 int icpx_icp_step(icpx_ctx* ctx, const double T[16], double sums[ICPX_NSUMS], int32_t* idx_opt, int idx_where);
 
 /* Same, but only enqueued: sums_dev is DEVICE memory (16 doubles) valid after icpx_sync() or after
