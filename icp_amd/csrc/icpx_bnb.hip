@@ -214,15 +214,16 @@ extern "C" int icpx_bnb_eval(icpx_ctx* ctx, const icpx_bnb_item* items, size_t n
     if (nitems == 0) return ICPX_OK;
     if (!ub || !lb) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval: ub / lb is NULL");
     ICPX_TRY(icpx_bind(ctx));
-    ICPX_TRY(icpx_reserve(ctx, ctx->bnb_out, 2 * nitems * sizeof(double)));
     float* md = nullptr;
     if (mindis_opt) {
         ICPX_TRY(icpx_reserve(ctx, ctx->bnb_mindis, nitems * ctx->nd * sizeof(float)));
         md = ctx->bnb_mindis.as<float>();
     }
-    ICPX_TRY(bnb_enqueue(ctx, items, nitems, ctx->bnb_out.as<double>(), md));
+    // The reduction kernel writes the bounds into the pinned staging buffer itself (behind the items): one copy
+    // command fewer per batch. The buffer is sized here so that the address is known before the launch.
+    ICPX_TRY(bnb_pin_reserve(ctx, nitems * sizeof(icpx_bnb_item) + 2 * nitems * sizeof(double)));
     double* res = reinterpret_cast<double*>(static_cast<char*>(ctx->bnb_pin) + nitems * sizeof(icpx_bnb_item));
-    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(res, ctx->bnb_out.p, 2 * nitems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_TRY(bnb_enqueue(ctx, items, nitems, res, md));
     if (mindis_opt)
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(mindis_opt, md, nitems * ctx->nd * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));

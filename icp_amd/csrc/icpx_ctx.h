@@ -84,7 +84,7 @@ struct icpx_ctx {
     size_t nd = 0;
     DevBuf data_pts;         // nd x float4 {x, y, z, bits(original index)}, spatially sorted
     DevBuf maxrot;           // ICPX_MAXROTLEVEL x nd float, sorted order
-    DevBuf bnb_items, bnb_partials, bnb_out, bnb_mindis;
+    DevBuf bnb_items, bnb_partials, bnb_mindis;
     double* pin_sums = nullptr;  // pinned host memory for the ICPX_NSUMS sums of an ICP pass: the reduction kernel writes them there itself
     void* bnb_pin = nullptr;     // pinned host staging of a bound batch: the items going up, then ub / lb coming down
     size_t bnb_pin_cap = 0;
