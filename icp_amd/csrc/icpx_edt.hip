@@ -305,7 +305,7 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
     int d, dd, w;
     if constexpr (!POOL) {
         // The pop loop and the crossing, by hand. The loop runs while any lane of the wave has to pop and is
-        // predicated instead of divergent (lanes that are done re-read the entry they already hold): 16
+        // predicated instead of divergent (lanes that are done re-read the entry they already hold): 18
         // instructions per round where the compiled divergent loop needs about 30, most of them mask
         // bookkeeping, and a wave issues one instruction every eight cycles or so whatever its kind. The
         // sentinel row makes "stack empty" a case of the same test: 0 * d + (0 - au) > 0 is false. The
@@ -320,6 +320,11 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
             "v_sub_u32 %[d], %[u], %[d]\n"
             "v_sub_u32 %[dd], %[dd], %[au]\n"
             "v_mad_i32_i24 %[x], %[tt2], %[d], %[dd]\n"
+            // pop while x > 0 and q >= 0, i.e. min(x, q + 1) > 0. With sane input the sentinel already fails x > 0;
+            // the second condition ends the loop whatever the input (pass x also runs on what an overflowed pass
+            // zy left behind, before the build is repeated: values there can be anything, negative included)
+            "v_add_u32 %[y], 1, %[q]\n"
+            "v_min_i32 %[x], %[x], %[y]\n"
             "v_cmp_lt_i32 vcc, 0, %[x]\n"
             "s_cbranch_vccz Lenv_done_%=\n"
             "s_waitcnt lgkmcnt(0)\n"

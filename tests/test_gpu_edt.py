@@ -63,6 +63,28 @@ def test_edt_dense_random_and_spill(gpu_ctx, oracle):
     assert gpu_ctx.edt_info()["dropped"] == dropped
 
 
+def test_edt_shape_adapted_to_one_cloud_then_another(oracle, bunny045):
+    """The stacks are shaped after the first cloud (all levels private, no pool); a cloud with much deeper stacks
+    then overflows both passes in its first attempt — pass x runs on whatever the overflowed pass zy left — and
+    the repeated build must still be exact (and nothing may hang on the way)."""
+    from icp_amd.api import Context
+    ctx = Context(0)
+    div = 200
+    for _ in range(2):
+        _build_and_check(ctx, oracle, bunny045, div)
+    rng = np.random.default_rng(23)
+    for n in (30000, 300000):
+        pts = rng.uniform(0.0, 1.0, (n, 3)).astype(np.float32)
+        mn = np.zeros(3, np.float32); cell = np.float32(1.0 / div)
+        ctx.set_target(pts)
+        ctx.edt_build(div, box=(mn, cell))
+        occ, _ = oracle.ldt_splat(pts, div, mn, cell)
+        assert np.array_equal(ctx.edt_read(), oracle.edt_meijster(occ))
+        _build_and_check(ctx, oracle, bunny045, div)      # and back: shaped for the dense cloud, run on the sparse one
+        _build_and_check(ctx, oracle, bunny045, div)
+    ctx.close()
+
+
 def test_edt_large_div(gpu_ctx, oracle, bunny045):
     """div > 511: ten-bit site indices and values above 2^19 in the packed stack entries."""
     _build_and_check(gpu_ctx, oracle, np.ascontiguousarray(bunny045[::3]), 520)
