@@ -37,8 +37,8 @@ struct icpx_ctx {
     float gmin[3] = {0, 0, 0};
     float gh = 0.f, ginv = 0.f;
     DevBuf cell_range;       // ncells x int2 {first, last} into sorted_pts
-    DevBuf pyr_flags;        // occupancy pyramid above the cells: one byte per cell of every level >= 1
-    DevBuf pyr_tab;          // 11 unsigned: offset of every level inside pyr_flags
+    DevBuf pyr_masks;        // occupancy pyramid above the cells: one byte per node of every level >= 1, the mask of its children that hold points
+    DevBuf pyr_tab;          // 11 unsigned: offset of every level inside pyr_masks
     int pyr_nlev = 0;        // levels including level 0 (the cells)
     int pyr_dim[11][3] = {};
     unsigned pyr_off[11] = {};

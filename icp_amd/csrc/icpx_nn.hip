@@ -4,7 +4,7 @@
 // SingleThreadIcp (kdtree_search src/SingleThreadIcp.cpp:186-214, cal_covarance :216-247, the residual
 // of best_fit_transform :281-287). Results are exact: every candidate distance is the reference's
 // double-precision expression ((dx*dx + dy*dy) + dz*dz) without fused multiply-add (this file is built
-// with -ffp-contract=off), ties resolve to the lowest target index, and cells / rings are skipped only
+// with -ffp-contract=off), ties resolve to the lowest target index, and cells / subtrees are skipped only
 // when a conservative lower bound on their distance is strictly larger than the best distance so far.
 //
 // Layout: target points sorted by cell (stable, so ascending original index inside a cell) as
@@ -33,8 +33,8 @@ struct GridView {
     float minx, miny, minz, h, inv;
     const int2* __restrict__ range;
     const float4* __restrict__ pts;
-    const unsigned char* __restrict__ flags;   // child masks of all levels >= 1, level l at flags + loff[l]
-    const unsigned* __restrict__ loff;          // MAXLEV offsets into flags (device memory)
+    const unsigned char* __restrict__ masks;   // child masks of all levels >= 1, level l at masks + loff[l]
+    const unsigned* __restrict__ loff;          // MAXLEV offsets into masks (device memory)
     int nlev;                                   // number of levels including level 0
 };
 
@@ -280,7 +280,7 @@ __device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsi
         const unsigned node = snode[sp * NN_OCTETS + oc];
         if (slb[sp * NN_OCTETS + oc] > b.bound()) continue;
         const int l = (int)(node >> 27), ni = (int)((node >> 18) & 511), nj = (int)((node >> 9) & 511), nk = (int)(node & 511);
-        const unsigned m = g.flags[loff[l] + ((size_t)ni * lev_dim(g.dy, l) + nj) * lev_dim(g.dz, l) + nk];
+        const unsigned m = g.masks[loff[l] + ((size_t)ni * lev_dim(g.dy, l) + nj) * lev_dim(g.dz, l) + nk];
         const int cl = l - 1;
         const double cside = h * (double)(1 << cl);
         const int ci = 2 * ni + (c >> 2), cj = 2 * nj + ((c >> 1) & 1), ck = 2 * nk + (c & 1);
@@ -526,7 +526,7 @@ GridView view_of(const icpx_ctx* ctx) {
     g.h = ctx->gh; g.inv = ctx->ginv;
     g.range = ctx->cell_range.as<int2>();
     g.pts = ctx->sorted_pts.as<float4>();
-    g.flags = ctx->pyr_flags.as<unsigned char>();
+    g.masks = ctx->pyr_masks.as<unsigned char>();
     g.loff = ctx->pyr_tab.as<unsigned>();
     g.nlev = ctx->pyr_nlev;
     return g;
@@ -607,9 +607,9 @@ int icpx_grid_build(icpx_ctx* ctx) {
         ctx->pyr_nlev = nlev;
         ICPX_TRY(icpx_reserve(ctx, ctx->pyr_tab, MAXLEV * sizeof(unsigned)));
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->pyr_tab.p, ctx->pyr_off, MAXLEV * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-        ICPX_TRY(icpx_reserve(ctx, ctx->pyr_flags, off ? off : 4));
-        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->pyr_flags.p, 0, off ? off : 4, ctx->stream));
-        unsigned char* fl = ctx->pyr_flags.as<unsigned char>();
+        ICPX_TRY(icpx_reserve(ctx, ctx->pyr_masks, off ? off : 4));
+        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->pyr_masks.p, 0, off ? off : 4, ctx->stream));
+        unsigned char* fl = ctx->pyr_masks.as<unsigned char>();
         for (int l = 1; l < nlev; l++) {
             const int* lo = ctx->pyr_dim[l - 1]; const int* up = ctx->pyr_dim[l];
             const size_t cells = (size_t)lo[0] * lo[1] * lo[2];
