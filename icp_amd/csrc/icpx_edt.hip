@@ -627,8 +627,9 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_zy(const RowRec* __res
 // Workgroup = row y, 64 consecutive z; lane = z. Sites are the non-empty planes; wave g scans the g-th
 // part of the plane list, fetching the in-plane distances EDT_PF planes ahead (the list is padded, so
 // the group loads need no bounds checks; indices are wave-uniform scalar loads, values one coalesced load
-// per plane).
-constexpr int EDT_PF = 8;
+// per plane). Measured on the 300^3 bunny grid: 50.2 / 47.2 / 47.5 / 47.7 / 48.6 / 52.7 us for 1 / 2 / 3 / 4 / 8 / 16
+// planes ahead (three workgroups a CU cover the latency between them; deeper prefetch only costs registers).
+constexpr int EDT_PF = 2;
 // Read-back helpers of the default shape (4 site groups): 2 = as many waves again. Measured on the 300^3
 // bunny grid: pass zy 34.8 / 30.3 / 31.5 / 32.1 us and pass x 65.4 / 58.9 / 70.7 / 73.0 us for 1 / 2 / 3 / 4
 // (from 3 on a CU no longer holds three workgroups of pass x).
