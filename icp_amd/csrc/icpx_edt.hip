@@ -628,8 +628,9 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_zy(const RowRec* __res
 // part of the plane list, fetching the in-plane distances EDT_PF planes ahead (the list is padded, so
 // the group loads need no bounds checks; indices are wave-uniform scalar loads, values one coalesced load
 // per plane). Measured on the 300^3 bunny grid: 50.2 / 47.2 / 47.5 / 47.7 / 48.6 / 52.7 us for 1 / 2 / 3 / 4 / 8 / 16
-// planes ahead (three workgroups a CU cover the latency between them; deeper prefetch only costs registers).
-constexpr int EDT_PF = 2;
+// planes ahead without the pool (three workgroups a CU cover the latency between them; deeper prefetch only costs
+// registers); the pool variant, which the larger grids run, does better with eight (768^3: 1.08 against 1.18 ms a build).
+template <bool POOL> constexpr int EDT_PF = POOL ? 8 : 2;
 // Read-back helpers of the default shape (4 site groups): 2 = as many waves again. Measured on the 300^3
 // bunny grid: pass zy 34.8 / 30.3 / 31.5 / 32.1 us and pass x 65.4 / 58.9 / 70.7 / 73.0 us for 1 / 2 / 3 / 4
 // (from 3 on a CU no longer holds three workgroups of pass x).
@@ -639,6 +640,7 @@ template <int G, bool POOL, int RB>
 __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restrict__ plane, const int* __restrict__ planelist,
                                                        u64* __restrict__ counters, int* __restrict__ sq, uint2* __restrict__ spill_buf,
                                                        int div, int nchunk, int cap, int nch, int report) {
+    constexpr int PF = EDT_PF<POOL>;
     extern __shared__ unsigned lds[];
     const int y = blockIdx.x / nchunk, c = blockIdx.x % nchunk;
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -652,21 +654,21 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restric
         const int klo = np * g / G, khi = np * (g + 1) / G;
         EnvTop e;
         env_init(E, g, e);
-        int Gn[EDT_PF], Un[EDT_PF];
+        int Gn[PF], Un[PF];
     #pragma unroll
-        for (int j = 0; j < EDT_PF; j++) Un[j] = planelist[klo + j];
+        for (int j = 0; j < PF; j++) Un[j] = planelist[klo + j];
     #pragma unroll
-        for (int j = 0; j < EDT_PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
-        for (int k0 = klo; k0 < khi; k0 += EDT_PF) {
-            int Gc[EDT_PF], Uc[EDT_PF];
+        for (int j = 0; j < PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
+        for (int k0 = klo; k0 < khi; k0 += PF) {
+            int Gc[PF], Uc[PF];
     #pragma unroll
-            for (int j = 0; j < EDT_PF; j++) { Gc[j] = Gn[j]; Uc[j] = Un[j]; }
+            for (int j = 0; j < PF; j++) { Gc[j] = Gn[j]; Uc[j] = Un[j]; }
     #pragma unroll
-            for (int j = 0; j < EDT_PF; j++) Un[j] = planelist[k0 + EDT_PF + j];
+            for (int j = 0; j < PF; j++) Un[j] = planelist[k0 + PF + j];
     #pragma unroll
-            for (int j = 0; j < EDT_PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
+            for (int j = 0; j < PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
     #pragma unroll
-            for (int j = 0; j < EDT_PF; j++)
+            for (int j = 0; j < PF; j++)
                 if (k0 + j < khi) env_add(E, g, e, Uc[j], Gc[j], div);
         }
         env_finish(E, g, e, e.deepest + 1, report ? &counters[7] : nullptr);
