@@ -727,18 +727,21 @@ static size_t edt_spill_bytes(const icpx_ctx* ctx) {
 }
 
 // Shapes the LDS of the envelope passes for later builds from the deepest stacks the last build saw: if
-// they fit a workgroup's private levels at three workgroups per CU, every level is private and the pool
-// is dropped (reads and writes above the private levels cost several times more); otherwise the default
+// they fit a workgroup's private levels at three workgroups per CU (pass x: two), every level is private and
+// the pool is dropped (reads and writes above the private levels cost several times more); otherwise the default
 // private levels plus pool stay. Shapes forced through the environment are left alone.
 static void edt_adapt(icpx_ctx* ctx, u64 deepest_zy, u64 deepest_x) {
     if (ctx->edt_tune_fixed) return;
     const EnvTune def{4, 28, 40};
-    const int cap_max = 33;   // 4 groups x (33 + 1 sentinel) rows x 384 B + 1 KiB header = 52 KiB: three workgroups per CU
+    // 4 groups x (33 + 1 sentinel) rows x 384 B + 1 KiB header = 52 KiB: three workgroups per CU. Pass x still gains
+    // from private levels alone at two workgroups per CU, up to 40 levels (64 000 B; bunny at 320^3 to 360^3,
+    // stacks of 35 to 38: 0.070 / 0.087 / 0.098 ms against 0.080 / 0.098 / 0.109 with the pool); pass zy does not.
+    const int cap_max[2] = {33, 40};
     const u64 d[2] = {deepest_zy, deepest_x};
     EnvTune* t[2] = {&ctx->edt_zy, &ctx->edt_x};
     bool fits = true;
     for (int k = 0; k < 2; k++) {
-        const bool f = d[k] >= 1 && d[k] <= (u64)cap_max;
+        const bool f = d[k] >= 1 && d[k] <= (u64)cap_max[k];
         *t[k] = f ? EnvTune{4, std::max((int)d[k], 8), 0} : def;
         fits = fits && f;
     }

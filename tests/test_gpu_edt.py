@@ -85,6 +85,18 @@ def test_edt_shape_adapted_to_one_cloud_then_another(oracle, bunny045):
     ctx.close()
 
 
+def test_edt_private_levels_at_two_workgroups_per_cu(oracle, bunny045):
+    """Just above the default resolution the stacks of pass x (36 levels at 340) no longer fit three workgroups per
+    CU; the builds after the first run pass x with private levels only in a larger workgroup."""
+    from icp_amd.api import Context
+    ctx = Context(0)
+    for _ in range(3):
+        sq, _, _ = _build_and_check(ctx, oracle, bunny045, 340)
+    ctx.edt_rebuild_async(); ctx.sync()
+    assert np.array_equal(ctx.edt_read(), sq)
+    ctx.close()
+
+
 def test_edt_large_div(gpu_ctx, oracle, bunny045):
     """div > 511: ten-bit site indices and values above 2^19 in the packed stack entries."""
     _build_and_check(gpu_ctx, oracle, np.ascontiguousarray(bunny045[::3]), 520)
