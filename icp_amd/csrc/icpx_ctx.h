@@ -65,9 +65,10 @@ struct icpx_ctx {
     bool edt_round = false;  // grid built with DT3D's convention: voxel = int((p - dmin) * scale + 0.5) in double
     double edt_dmin[3] = {0, 0, 0}, edt_scale = 0.0;
     // Envelope passes: site groups (= waves) per 64 rows, private LDS levels per lane and group, pool
-    // chunks per workgroup. 4 x 28 x 64 x 6 bytes + 40 chunks x 48 bytes + header = 47 KiB: three
-    // workgroups (12 waves) per CU; measured best on the 300^3 bunny grid among the shapes tried.
-    EnvTune edt_zy{4, 28, 40}, edt_x{4, 28, 40};
+    // chunks per workgroup. 4 x (28 + 1) x 64 x 6 bytes + 130 chunks x 48 bytes + header = 53 088 B: three
+    // workgroups per CU, as with the 40 chunks used at first; the larger pool takes 4 to 12 % off pass x on
+    // grids of 512^3 and more (bunny, 1023^3: 2.79 against 3.15 ms), whose deep stacks otherwise reach the spill tier.
+    EnvTune edt_zy{4, 28, 130}, edt_x{4, 28, 130};
     bool edt_tune_fixed = false;   // shapes came from the environment: do not adapt them to the data
     bool edt_overflowed = false;   // a build needed levels beyond the private ones: use the kernels with pool / spill tiers
     DevBuf edt_bits;         // div*div*edt_words uint64 occupancy bits, then two sets of 8 uint64 counters (alternate builds)

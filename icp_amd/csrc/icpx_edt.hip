@@ -732,7 +732,7 @@ static size_t edt_spill_bytes(const icpx_ctx* ctx) {
 // private levels plus pool stay. Shapes forced through the environment are left alone.
 static void edt_adapt(icpx_ctx* ctx, u64 deepest_zy, u64 deepest_x) {
     if (ctx->edt_tune_fixed) return;
-    const EnvTune def{4, 28, 40};
+    const EnvTune def{4, 28, 130};
     // 4 groups x (33 + 1 sentinel) rows x 384 B + 1 KiB header = 52 KiB: three workgroups per CU. Pass x still gains
     // from private levels alone at two workgroups per CU, up to 40 levels (64 000 B; bunny at 320^3 to 360^3,
     // stacks of 35 to 38: 0.070 / 0.087 / 0.098 ms against 0.080 / 0.098 / 0.109 with the pool); pass zy does not.
