@@ -223,30 +223,24 @@ DT3D::DT3D(DevicePtr d) : SIZE(300), scale(0), expandFactor(2.0), xMin(0), xMax(
 
 void DT3D::Build(const double* x, const double* y, const double* z, int num) {
     if (!x || !y || !z || num < 1) throw IcpxFailure(ICPX_EINVAL, "DT3D::Build: empty cloud");
-    xMin = xMax = x[0]; yMin = yMax = y[0]; zMin = zMax = z[0];
-    for (int i = 1; i < num; i++) {
-        if (xMin > x[i]) xMin = x[i];
-        if (xMax < x[i]) xMax = x[i];
-        if (yMin > y[i]) yMin = y[i];
-        if (yMax < y[i]) yMax = y[i];
-        if (zMin > z[i]) zMin = z[i];
-        if (zMax < z[i]) zMax = z[i];
-    }
-    // :743-764, statement by statement (the second assignment of each pair sees the first)
-    const double xCenter = (xMin + xMax) / 2, yCenter = (yMin + yMax) / 2, zCenter = (zMin + zMax) / 2;
-    xMin = xCenter - expandFactor * (xMax - xCenter);
-    xMax = xCenter + expandFactor * (xMax - xCenter);
-    yMin = yCenter - expandFactor * (yMax - yCenter);
-    yMax = yCenter + expandFactor * (yMax - yCenter);
-    zMin = zCenter - expandFactor * (zMax - zCenter);
-    zMax = zCenter + expandFactor * (zMax - zCenter);
-    double max = xMax - xMin > yMax - yMin ? xMax - xMin : yMax - yMin;
-    max = max > zMax - zMin ? max : zMax - zMin;
-    xMin = xCenter - max / 2; xMax = xCenter + max / 2;
-    yMin = yCenter - max / 2; yMax = yCenter + max / 2;
-    zMin = zCenter - max / 2; zMax = zCenter + max / 2;
+    // Per axis (:732-756): extent of the coordinates, centre, then the extent stretched about the centre by
+    // expandFactor; afterwards (:757-764) every axis gets the longest stretched side, again about its centre.
+    struct Span { double lo, hi, mid; };
+    auto stretched = [&](const double* v) {
+        Span a{v[0], v[0], 0.0};
+        for (int i = 1; i < num; i++) { a.lo = std::min(a.lo, v[i]); a.hi = std::max(a.hi, v[i]); }
+        a.mid = (a.lo + a.hi) / 2;
+        const double reach = expandFactor * (a.hi - a.mid);
+        a.lo = a.mid - reach; a.hi = a.mid + reach;
+        return a;
+    };
+    Span ax[3] = {stretched(x), stretched(y), stretched(z)};
+    double side = ax[0].hi - ax[0].lo;
+    for (int c = 1; c < 3; c++) side = std::max(side, ax[c].hi - ax[c].lo);
+    for (Span& a : ax) { a.lo = a.mid - side / 2; a.hi = a.mid + side / 2; }
+    xMin = ax[0].lo; xMax = ax[0].hi; yMin = ax[1].lo; yMax = ax[1].hi; zMin = ax[2].lo; zMax = ax[2].hi;
     SIZE = 300;
-    scale = SIZE / max;
+    scale = SIZE / side;
     cloud_ = std::make_shared<PointCloudT>();
     cloud_->points.resize((size_t)num);
     for (int i = 0; i < num; i++) cloud_->points[i] = Point3f((float)x[i], (float)y[i], (float)z[i]);
@@ -669,18 +663,22 @@ float GoIcp::innerBnB(float* maxDistL, TransNode* transOut) {
     return s.optErrorT;
 }
 
-// Rodrigues matrix of the cube centre in float (src/GoIcp.cpp:243-261). Returns false when t == 0.
+// Rodrigues matrix of the cube centre in float (src/GoIcp.cpp:243-261): R = cos t I + (1 - cos t) n n^T + sin t [n]x
+// for the unit axis n = v / t, every entry formed as (n_i n_j)(1 - cos t) first and the cos / sin term added or
+// subtracted last, which is the rounding order of the reference's temporaries. Returns false when t == 0.
 static bool rotation_of(float v1, float v2, float v3, float R[9]) {
-    const float t = std::sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+    float n[3] = {v1, v2, v3};
+    const float t = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
     if (!(t > 0)) { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0); return false; }
-    v1 /= t; v2 /= t; v3 /= t;
-    const float ct = std::cos(t), ct2 = 1 - ct, st = std::sin(t);
-    const float tmp121 = v1 * v2 * ct2, tmp122 = v3 * st;
-    const float tmp131 = v1 * v3 * ct2, tmp132 = v2 * st;
-    const float tmp231 = v2 * v3 * ct2, tmp232 = v1 * st;
-    R[0] = ct + v1 * v1 * ct2; R[1] = tmp121 - tmp122; R[2] = tmp131 + tmp132;
-    R[3] = tmp121 + tmp122; R[4] = ct + v2 * v2 * ct2; R[5] = tmp231 - tmp232;
-    R[6] = tmp131 - tmp132; R[7] = tmp231 + tmp232; R[8] = ct + v3 * v3 * ct2;
+    for (float& c : n) c /= t;
+    const float cs = std::cos(t), vers = 1 - cs, sn = std::sin(t);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            const float outer = n[std::min(i, j)] * n[std::max(i, j)] * vers;
+            if (i == j) { R[3 * i + j] = cs + outer; continue; }
+            const float cross = n[3 - i - j] * sn;                     // the axis component that is neither i nor j
+            R[3 * i + j] = (j - i + 3) % 3 == 1 ? outer - cross : outer + cross;
+        }
     return true;
 }
 

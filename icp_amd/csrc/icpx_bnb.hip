@@ -126,7 +126,9 @@ extern "C" int icpx_goicp_set_data(icpx_ctx* ctx, const float* xyz, size_t n, si
     ICPX_TRY(icpx_stage_points4(ctx, xyz, n, stride_bytes, where, ctx->data_pts.as<float4>()));
     ICPX_TRY(icpx_morton_sort4(ctx, ctx->data_pts.as<float4>(), n));
     RotConsts rc;
-    const double initRotW = 2 * GOICP_PI;   // InitRot.w, src/GoIcp.cpp:88
+    // InitRot.w is a float member (RotNode, src/GoIcp.cpp:26): the 2*PI assigned at :88 is rounded to float and :472
+    // widens that float, not the double product
+    const double initRotW = (double)(float)(2 * GOICP_PI);
     for (int l = 0; l < ICPX_MAXROTLEVEL; l++) {
         const double sigma = initRotW / std::pow(2.0, l) / 2.0;
         double tmp = sigma * GOICP_SQRT3;

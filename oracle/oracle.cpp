@@ -749,7 +749,9 @@ void orc_ldt_lookup(const int32_t* sq, uint32_t div, const float* min3, float ce
 
 // GoIcp::Init's rotation-uncertainty table (src/GoIcp.cpp:462-480): out is 20 x n floats.
 void orc_goicp_maxrotdist(const float* data, int64_t n, float* out) {
-    const double initRotW = 2 * ORC_PI;
+    // InitRot.w is a float member of RotNode (src/GoIcp.cpp:26), so the 2*PI stored at :88 is rounded to float
+    // before :472 widens it again
+    const double initRotW = (double)(float)(2 * ORC_PI);
     for (int l = 0; l < ORC_MAXROTLEVEL; l++) {
         double sigma = initRotW / std::pow(2.0, l) / 2.0;
         double tmp = sigma * ORC_SQRT3;

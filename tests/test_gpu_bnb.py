@@ -22,7 +22,14 @@ def test_bounds_match_oracle(gpu_ctx, oracle, bunny000, bun270):
     sq = gpu_ctx.edt_read()
     gpu_ctx.goicp_set_data(data)
     # maxRotDist table
-    assert np.array_equal(gpu_ctx.goicp_maxrotdist(), oracle.goicp_maxrotdist(data))
+    table = gpu_ctx.goicp_maxrotdist()
+    assert np.array_equal(table, oracle.goicp_maxrotdist(data))
+    # and against the formula itself, independent of the oracle: InitRot.w is a float (src/GoIcp.cpp:26, :88, :472)
+    nrm = np.sqrt((data[:, 0] * data[:, 0] + data[:, 1] * data[:, 1]) + data[:, 2] * data[:, 2]).astype(np.float64)
+    w0 = float(np.float32(2 * 3.1415926536))
+    for l in range(20):
+        tmp = min(w0 / 2.0 ** l / 2.0 * 1.732050808, 3.1415926536)
+        assert np.array_equal(table[l], (2 * np.sin(tmp / 2) * nrm).astype(np.float32)), l
     rng = np.random.default_rng(2)
     R = oracle.goicp_rotmat(np.array([0.4, -1.1, 0.7], np.float32))
     rotated = oracle.goicp_rotate(R, data)

@@ -27,6 +27,11 @@ def test_edt_bunny_small(gpu_ctx, oracle, bunny045, div):
 def test_edt_bunny_300_and_lookup(gpu_ctx, oracle, bunny045, bunny000):
     sq, mn, cell = _build_and_check(gpu_ctx, oracle, bunny045, 300)
     assert cell == np.float32(0.0011251526)
+    # the committed hash of the grid, which the CPU suite checks voxel by voxel against scipy's exact transform
+    import hashlib, json, os
+    from conftest import GOLDEN
+    g = json.load(open(os.path.join(GOLDEN, "edt_bunny045.json")))["300"]
+    assert hashlib.sha256(sq.astype("<i4").tobytes()).hexdigest() == g["sha256"]
     # lookup: in-box queries (bunny000) and queries far outside the box
     rng = np.random.default_rng(3)
     far = (rng.uniform(-1, 1, (5000, 3))).astype(np.float32)
