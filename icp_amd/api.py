@@ -217,6 +217,11 @@ class Context:
                                          lb.ctypes.data_as(C.c_void_p), md.ctypes.data_as(C.c_void_p) if want_mindis else None))
         return (ub, lb, md) if want_mindis else (ub, lb)
 
+    def bnb_eval_noalloc(self, items_dev, nitems, out_dev):
+        """icpx_bnb_eval_noalloc: items_dev a CUDA uint8 tensor holding `nitems` packed icpx_bnb_item records, out_dev a
+        CUDA float64 tensor of 2 * nitems ([ub..., lb...]). Only enqueues on the context's stream: sync() before reading."""
+        self._ck(self._lib.icpx_bnb_eval_noalloc(self._h, C.c_void_p(items_dev.data_ptr()), nitems, C.c_void_p(out_dev.data_ptr())))
+
     def goicp_residuals(self, T):
         T = np.ascontiguousarray(T, np.float64).reshape(16)
         out = np.empty(self._nd, np.float32)

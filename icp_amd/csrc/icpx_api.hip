@@ -77,6 +77,12 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
             g * 384 + 768 + g * (c + 1) * 384 + n * 48 <= 65536)
             { (k ? ctx->edt_x : ctx->edt_zy) = EnvTune{g, c, n}; ctx->edt_tune_fixed = true; }
     }
+    if (icpx_bnb_scratch_init(ctx) != ICPX_OK) {
+        g_create_error = "icpx_create: " + ctx->err;
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return ICPX_EHIP;
+    }
     *out = ctx;
     return ICPX_OK;
 }

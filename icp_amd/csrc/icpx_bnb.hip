@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void k_bnb_eval(EdtView e, const float4* __res
     const float half = it.w / 2;
     const float tx = it.x + half, ty = it.y + half, tz = it.z + half;
     const float maxTransDis = (float)(GOICP_SQRT3 / 2.0 * (double)it.w);
-    const float* mr = it.level >= 0 ? maxrot + (size_t)it.level * n : nullptr;
+    // items that arrive in device memory cannot be checked by the host: a level beyond the table reads nothing and
+    // yields NaN bounds
+    const bool bad_level = it.level >= ICPX_MAXROTLEVEL;
+    const float* mr = it.level >= 0 && !bad_level ? maxrot + (size_t)it.level * n : nullptr;
     const size_t per = (n + nsplit - 1) / nsplit;
     const size_t lo = (size_t)split * per, hi = lo + per < n ? lo + per : n;
     double ub = 0.0, lb = 0.0;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void k_bnb_eval(EdtView e, const float4* __res
     __syncthreads();
     if (threadIdx.x < 2) {
         const double v = (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
-        partials[((size_t)item * nsplit + split) * 2 + threadIdx.x] = v;
+        partials[((size_t)item * nsplit + split) * 2 + threadIdx.x] = bad_level ? (double)NAN : v;
     }
 }
 
@@ -171,6 +174,28 @@ extern "C" int icpx_goicp_read_maxrotdist(icpx_ctx* ctx, float* out) {
 #define ICPX_BNB_SLICES 16
 #endif
 
+// Slices per item: a function of the cloud alone, never of the batch, so that the bounds of a cube are the same
+// bits whichever cubes it shares a launch with (the partial sums are added in slice order).
+static int bnb_slices(size_t n) {
+    const int nsplit = (int)std::min<size_t>((n + 1023) / 1024, ICPX_BNB_SLICES);
+    return nsplit < 1 ? 1 : nsplit;
+}
+
+// Partial sums of icpx_bnb_eval_noalloc: {ub, lb} per (item, slice), ICPX_NOALLOC_MAX_ITEMS x ICPX_BNB_SLICES x 2
+// doubles = 1 MiB, part of the code object, so every GPU the library runs on holds its own copy at its own
+// address until the process ends. In host code the array's name is only a handle for hipGetSymbolAddress: the
+// address kernels and copies use is the one icpx_bnb_scratch_init stores in the context.
+static __device__ __align__(256) double scratch[(size_t)ICPX_NOALLOC_MAX_ITEMS * ICPX_BNB_SLICES * 2];
+
+// Called by icpx_create with the context's device current.
+int icpx_bnb_scratch_init(icpx_ctx* ctx) {
+    void* ptr = nullptr;
+    ICPX_CHECK_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) ICPX_FAIL(ctx, ICPX_EHIP, "hipGetSymbolAddress returned no address for the bound scratch array");
+    ctx->bnb_scratch = static_cast<double*>(ptr);
+    return ICPX_OK;
+}
+
 static int bnb_pin_reserve(icpx_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->bnb_pin_cap) return ICPX_OK;
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -189,10 +214,7 @@ static int bnb_enqueue(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems,
     for (size_t i = 0; i < nitems; i++)
         if (items[i].level >= ICPX_MAXROTLEVEL) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval: item %zu has level %d >= %d", i, items[i].level, ICPX_MAXROTLEVEL);
     const size_t n = ctx->nd;
-    // Slices per item: a function of the cloud alone, never of the batch, so that the bounds of a cube are the
-    // same bits whichever cubes it shares a launch with (the partial sums are added in slice order).
-    int nsplit = (int)std::min<size_t>((n + 1023) / 1024, ICPX_BNB_SLICES);
-    if (nsplit < 1) nsplit = 1;
+    const int nsplit = bnb_slices(n);
     ICPX_TRY(icpx_reserve(ctx, ctx->bnb_items, nitems * sizeof(icpx_bnb_item)));
     ICPX_TRY(icpx_reserve(ctx, ctx->bnb_partials, nitems * nsplit * 2 * sizeof(double)));
     // The item list goes through the pinned buffer (front part; the results come back into the part behind
@@ -240,6 +262,27 @@ extern "C" int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, si
     if (!out_dev) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval_async: out_dev is NULL");
     ICPX_TRY(icpx_bind(ctx));
     return bnb_enqueue(ctx, items, nitems, out_dev, nullptr);
+}
+
+extern "C" int icpx_bnb_eval_noalloc(icpx_ctx* ctx, const icpx_bnb_item* items_dev, size_t nitems, double* out_dev) {
+    if (!ctx) return ICPX_EINVAL;
+    if (nitems == 0) return ICPX_OK;
+    if (!items_dev || !out_dev) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval_noalloc: NULL buffer");
+    if (nitems > ICPX_NOALLOC_MAX_ITEMS)
+        ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_bnb_eval_noalloc: %zu items exceed the fixed scratch area (at most %d per call)", nitems, ICPX_NOALLOC_MAX_ITEMS);
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_eval_noalloc: no EDT has been built");
+    if (ctx->nd == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_eval_noalloc: no data cloud (call icpx_goicp_set_data first)");
+    if (!ctx->bnb_scratch) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_eval_noalloc: the scratch area was not resolved at icpx_create");
+    ICPX_TRY(icpx_bind(ctx));
+    const size_t n = ctx->nd;
+    const int nsplit = bnb_slices(n);
+    // Every {ub, lb} slot that k_bnb_reduce reads is written by k_bnb_eval of this same call, so nothing left in the
+    // area by an earlier (possibly larger) batch is ever read and no clearing is needed.
+    double* part = ctx->bnb_scratch;
+    hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nitems, (unsigned)nsplit), dim3(256), 0, ctx->stream, edt_view(ctx),
+                       ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), items_dev, nsplit, part, (float*)nullptr);
+    hipLaunchKernelGGL(k_bnb_reduce, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, ctx->stream, part, (int)nitems, nsplit, out_dev);
+    return icpx_launch_check(ctx, "k_bnb_eval (noalloc)");
 }
 
 extern "C" int icpx_goicp_residuals(icpx_ctx* ctx, const double T[16], float* dist_out) {

@@ -87,6 +87,7 @@ struct icpx_ctx {
     DevBuf maxrot;           // ICPX_MAXROTLEVEL x nd float, sorted order
     DevBuf bnb_items, bnb_partials, bnb_mindis;
     double* pin_sums = nullptr;  // pinned host memory for the ICPX_NSUMS sums of an ICP pass: the reduction kernel writes them there itself
+    double* bnb_scratch = nullptr;   // this GPU's address of the fixed partial-sum area of icpx_bnb_eval_noalloc (resolved at icpx_create)
     void* bnb_pin = nullptr;     // pinned host staging of a bound batch: the items going up, then ub / lb coming down
     size_t bnb_pin_cap = 0;
 
@@ -133,5 +134,7 @@ int icpx_morton_sort4(icpx_ctx* ctx, float4* pts, size_t n);
 
 // icpx_nn.hip
 int icpx_grid_build(icpx_ctx* ctx);
+// icpx_bnb.hip
+int icpx_bnb_scratch_init(icpx_ctx* ctx);
 // icpx_edt.hip
 int icpx_edt_run(icpx_ctx* ctx, bool report);

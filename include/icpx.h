@@ -201,6 +201,18 @@ int icpx_bnb_eval(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, doub
  * one pinned staging area per context: the call first waits for earlier work on the context's stream). */
 int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev);
 
+/* No counterpart in the reference. For callers that cannot allocate device memory while they run (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the same bounds as icpx_bnb_eval_async
+ * (bit for bit), enqueued on the context's stream, with no allocation of any kind inside the call. items_dev and
+ * out_dev (2 * nitems doubles, [ub..., lb...]) are DEVICE memory of the context's GPU; the per-slice partial sums
+ * go to a fixed 1 MiB area inside the library's code object instead of a grown buffer, which limits a call to
+ * ICPX_NOALLOC_MAX_ITEMS items (ICPX_ELIMIT beyond). An item whose level is >= ICPX_MAXROTLEVEL gets NaN bounds
+ * (the host cannot inspect device-resident items). All calls on one GPU share that area, whichever context they
+ * come through: calls that overlap in time on one GPU (different streams or contexts) race; calls on one stream
+ * are ordered and safe. Requires the EDT and the data cloud (icpx_goicp_set_data) to be in place already. */
+#define ICPX_NOALLOC_MAX_ITEMS 4096
+int icpx_bnb_eval_noalloc(icpx_ctx* ctx, const icpx_bnb_item* items_dev, size_t nitems, double* out_dev);
+
 /* Replaces the SSE loop of GoIcp::runICP (src/GoIcp.cpp:113-135) and the initial error of OuterBnB
  * (:161-172): d_i = Distance((float)(T * [x_i;1])) for the data cloud, T row-major 4x4 double (host);
  * writes every d_i (n floats, host, caller's order) so the caller can form the sequential float sum. */
