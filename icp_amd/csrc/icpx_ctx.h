@@ -36,7 +36,8 @@ struct icpx_ctx {
     int gdim[3] = {0, 0, 0};
     float gmin[3] = {0, 0, 0};
     float gh = 0.f, ginv = 0.f;
-    DevBuf cell_range;       // ncells x int2 {first, last} into sorted_pts
+    DevBuf cell_start;       // ncells + 1 int: position in sorted_pts of every cell's first point (exclusive prefix sum of the counts)
+    DevBuf cell_count;       // ncells + 1 int: points per cell (input of that prefix sum)
     DevBuf pyr_masks;        // occupancy pyramid above the cells: one byte per node of every level >= 1, the mask of its children that hold points
     DevBuf pyr_tab;          // 11 unsigned: offset of every level inside pyr_masks
     int pyr_nlev = 0;        // levels including level 0 (the cells)
@@ -48,7 +49,10 @@ struct icpx_ctx {
     // ---- source cloud (ICP) ----------------------------------------------------------------------
     size_t ns = 0;
     DevBuf src_pts;          // ns x float4 {x, y, z, bits(original index)}, spatially sorted
-    DevBuf nn_seed;          // ns int: target index each source point (sorted position) was paired with by the last ICP pass, -1 = none
+    DevBuf nn_seed;          // ns int, by sorted source position: position in sorted_pts of the target point the source point was paired with by the last ICP pass, -1 = none
+    DevBuf tile_counters;    // eight 64-bit counters, 64 B apart, that hand out the tiles of an ICP pass; never reset
+    unsigned long long tile_counter_base = 0;   // their common value before the next launch
+    DevBuf walk_queue;       // one ICP pass: per tile of 64 source points the number it left to the pyramid walk, then those points' positions (64 entries per tile)
     DevBuf partials;         // per-block partial sums
     DevBuf sums;             // ICPX_NSUMS doubles
     DevBuf scratch_q, scratch_idx, scratch_d2, scratch_f;   // staging for host-pointer calls

@@ -8,13 +8,19 @@
 // when a conservative lower bound on their distance is strictly larger than the best distance so far.
 //
 // Layout: target points sorted by cell (stable, so ascending original index inside a cell) as
-// float4 {x, y, z, bits(index)}; cell_range[cell] = {first, last}. Queries of the ICP step are the
-// source cloud in Morton order, so neighbouring lanes walk neighbouring cells.
+// float4 {x, y, z, bits(index)}; cell_start[cell] = position of the cell's first point in that order
+// (cell_start[cell + 1] its end; cells are numbered (x * dy + y) * dz + z, so the points of a run of cells along z
+// are one contiguous run). Queries of the ICP step are the source cloud in Morton order, so the 64 queries of a
+// wave lie in a few neighbouring cells.
 #include "icpx_ctx.h"
+
+#include <rocprim/device/device_scan.hpp>
 
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <algorithm>
+#include <vector>
 
 int icpx_sort_pairs(icpx_ctx* ctx, size_t n, unsigned end_bit);
 int icpx_sort_pairs64(icpx_ctx* ctx, size_t n, const unsigned long long* keys_in, unsigned long long* keys_out, const unsigned* vals_in,
@@ -31,7 +37,7 @@ constexpr int MAXLEV = 11;
 struct GridView {
     int dx, dy, dz;
     float minx, miny, minz, h, inv;
-    const int2* __restrict__ range;
+    const int* __restrict__ start;             // ncells + 1 positions into pts
     const float4* __restrict__ pts;
     const unsigned char* __restrict__ masks;   // child masks of all levels >= 1, level l at masks + loff[l]
     const unsigned* __restrict__ loff;          // MAXLEV offsets into masks (device memory)
@@ -55,12 +61,17 @@ __global__ void k_cell_keys(const float4* __restrict__ pts, size_t n, GridView g
     vals[i] = (unsigned)i;
 }
 
-__global__ void k_cell_ranges(const unsigned* __restrict__ keys, size_t n, int2* __restrict__ range, unsigned* __restrict__ distinct) {
+// Points per cell from the sorted keys (one add per run of equal keys) and the number of occupied cells; the
+// exclusive prefix sum of the counts is cell_start.
+__global__ void k_cell_counts(const unsigned* __restrict__ keys, size_t n, int* __restrict__ count, unsigned* __restrict__ distinct) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned k = keys[i];
-    if (i == 0 || keys[i - 1] != k) { range[k].x = (int)i; if (distinct) atomicAdd(distinct, 1u); }
-    if (i == n - 1 || keys[i + 1] != k) range[k].y = (int)(i + 1);
+    if (i != 0 && keys[i - 1] == k) return;
+    size_t e = i + 1;
+    while (e < n && keys[e] == k) e++;
+    count[k] = (int)(e - i);
+    atomicAdd(distinct, 1u);
 }
 
 __global__ void k_gather_pts(const float4* __restrict__ src, const unsigned* __restrict__ order, size_t n, float4* __restrict__ dst) {
@@ -76,11 +87,10 @@ __device__ __forceinline__ void pyr_mark(unsigned* __restrict__ up, int cx, int 
     atomicOr(up + (parent >> 2), (1u << bit) << (8 * (parent & 3)));
 }
 
-__global__ void k_pyr_from_cells(const int2* __restrict__ range, int dx, int dy, int dz, unsigned* __restrict__ up, int uy, int uz) {
+__global__ void k_pyr_from_cells(const int* __restrict__ start, int dx, int dy, int dz, unsigned* __restrict__ up, int uy, int uz) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)dx * dy * dz) return;
-    const int2 r = range[i];
-    if (r.y <= r.x) return;
+    if (start[i + 1] <= start[i]) return;
     pyr_mark(up, (int)(i / ((size_t)dz * dy)), (int)((i / dz) % dy), (int)(i % dz), uy, uz);
 }
 
@@ -93,13 +103,13 @@ __global__ void k_pyr_from_masks(const unsigned char* __restrict__ lo, int dx, i
 
 // Search results. Candidates are ordered by (squared distance, index); bound() is the distance beyond which
 // nothing can enter any more.
-struct Best {               // the single nearest
+struct Best {               // the single nearest; pos = its position in the cell-sorted order (-1: none)
     double d2;
-    int idx;
-    __device__ __forceinline__ void init() { d2 = INFINITY; idx = 0x7fffffff; }
+    int idx, pos;
+    __device__ __forceinline__ void init() { d2 = INFINITY; idx = 0x7fffffff; pos = -1; }
     __device__ __forceinline__ double bound() const { return d2; }
-    __device__ __forceinline__ void offer(double d, int id) {
-        if (d < d2 || (d == d2 && id < idx)) { d2 = d; idx = id; }
+    __device__ __forceinline__ void offer(double d, int id, int at) {
+        if (d < d2 || (d == d2 && id < idx)) { d2 = d; idx = id; pos = at; }
     }
 };
 
@@ -112,7 +122,7 @@ struct BestK {              // the K nearest, ascending; unused slots hold (INFI
         for (int k = 0; k < K; k++) { d2[k] = INFINITY; idx[k] = 0x7fffffff; }
     }
     __device__ __forceinline__ double bound() const { return d2[K - 1]; }
-    __device__ __forceinline__ void offer(double d, int id) {
+    __device__ __forceinline__ void offer(double d, int id, int = 0) {
         if (!(d < d2[K - 1] || (d == d2[K - 1] && id < idx[K - 1]))) return;
         // one pass of insertion from the back: shift the larger entries up, drop the candidate in its place
 #pragma unroll
@@ -126,12 +136,12 @@ struct BestK {              // the K nearest, ascending; unused slots hold (INFI
 
 template <class R>
 __device__ __forceinline__ void scan_cell(const GridView& g, int cell, double qx, double qy, double qz, R& b) {
-    const int2 r = g.range[cell];
-    for (int k = r.x; k < r.y; k++) {
+    const int first = g.start[cell], last = g.start[cell + 1];
+    for (int k = first; k < last; k++) {
         const float4 p = g.pts[k];
         const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
         const double d = (dx * dx + dy * dy) + dz * dz;
-        b.offer(d, __float_as_int(p.w));
+        b.offer(d, __float_as_int(p.w), k);
     }
 }
 
@@ -178,8 +188,8 @@ __device__ __forceinline__ Best octet_min(Best b) {
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) {
         const double d = __shfl_xor(b.d2, o);
-        const int id = __shfl_xor(b.idx, o);
-        if (d < b.d2 || (d == b.d2 && id < b.idx)) { b.d2 = d; b.idx = id; }
+        const int id = __shfl_xor(b.idx, o), at = __shfl_xor(b.pos, o);
+        if (d < b.d2 || (d == b.d2 && id < b.idx)) { b.d2 = d; b.idx = id; b.pos = at; }
     }
     return b;
 }
@@ -195,7 +205,7 @@ struct OctK {
     BestK<K> g, l;
     __device__ __forceinline__ void init() { g.init(); l.init(); }
     __device__ __forceinline__ double bound() const { return g.d2[K - 1]; }
-    __device__ __forceinline__ void offer(double d, int id) {
+    __device__ __forceinline__ void offer(double d, int id, int = 0) {
         if (!(d < g.d2[K - 1] || (d == g.d2[K - 1] && id < g.idx[K - 1]))) return;
         l.offer(d, id);
     }
@@ -209,7 +219,7 @@ __device__ __forceinline__ void octet_merge(OctK<K>& b) {
 #pragma unroll
     for (int r = 0; r < K; r++) {
         Best head;
-        head.d2 = b.l.d2[0]; head.idx = b.l.idx[0];
+        head.d2 = b.l.d2[0]; head.idx = b.l.idx[0]; head.pos = -1;
         const Best m = octet_min(head);
         const bool from_g = b.g.d2[0] < m.d2 || (b.g.d2[0] == m.d2 && b.g.idx[0] <= m.idx);
         out.d2[r] = from_g ? b.g.d2[0] : m.d2;
@@ -231,13 +241,14 @@ __device__ __forceinline__ void octet_merge(OctK<K>& b) {
 constexpr int NN_OCTETS = 32;   // octets per 256-thread block
 constexpr int NN_STACK = 72;    // 1 + 7 entries for each of the (at most ten) levels above the cells, rounded up
 
-// `snode`, `slb`: the walk's stack in LDS, NN_STACK entries per octet, entry k of octet o at [k * NN_OCTETS + o];
+// `snode`, `slb`: the walk's stack in LDS, NN_STACK entries per octet, entry k of octet `oc` at [k * nocts + oc];
 // `b`: the result so far (Best or OctK<K>), initialised, the same in all lanes: empty, or holding candidates
 // that are real target points, e.g. the correspondence of the previous ICP iteration, whose distance then prunes
 // the search from the start; the result does not depend on them (equal distances still go to the lower index
 // because cells are only skipped when their bound is strictly larger).
 template <class R>
-__device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsigned* snode, double* slb, const unsigned* loff, R b) {
+__device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsigned* snode, double* slb, const int oc, const int nocts,
+                        const unsigned* loff, R b) {
     const int c = (int)(threadIdx.x & 7);
     const int cx = cell_coord((float)qx, g.minx, g.inv, g.dx), cy = cell_coord((float)qy, g.miny, g.inv, g.dy),
               cz = cell_coord((float)qz, g.minz, g.inv, g.dz);
@@ -271,14 +282,13 @@ __device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsi
     // farthest first (in the order of visit_order: the octant of the query, then one axis flipped, ...).
     // A node whose bound has been overtaken by the best distance since it was pushed is dropped when popped.
     // Depth: one pop and at most eight pushes per level, NN_STACK covers the ten levels above the cells.
-    const int oc = (int)(threadIdx.x >> 3);
     int sp = 1;
     snode[oc] = (unsigned)top << 27;
     slb[oc] = 0.0;
     while (sp > 0) {
         sp--;
-        const unsigned node = snode[sp * NN_OCTETS + oc];
-        if (slb[sp * NN_OCTETS + oc] > b.bound()) continue;
+        const unsigned node = snode[sp * nocts + oc];
+        if (slb[sp * nocts + oc] > b.bound()) continue;
         const int l = (int)(node >> 27), ni = (int)((node >> 18) & 511), nj = (int)((node >> 9) & 511), nk = (int)(node & 511);
         const unsigned m = g.masks[loff[l] + ((size_t)ni * lev_dim(g.dy, l) + nj) * lev_dim(g.dz, l) + nk];
         const int cl = l - 1;
@@ -302,8 +312,8 @@ __device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsi
         const int n = __popc(cand);
         if (ok) {
             const int at = sp + n - 1 - __popc(vis & ((1u << t) - 1u));
-            snode[at * NN_OCTETS + oc] = ((unsigned)cl << 27) | ((unsigned)ci << 18) | ((unsigned)cj << 9) | (unsigned)ck;
-            slb[at * NN_OCTETS + oc] = lb;
+            snode[at * nocts + oc] = ((unsigned)cl << 27) | ((unsigned)ci << 18) | ((unsigned)cj << 9) | (unsigned)ck;
+            slb[at * nocts + oc] = lb;
         }
         sp += n;
     }
@@ -312,18 +322,22 @@ __device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsi
 
 __device__ __forceinline__ Best best_empty() { Best b; b.init(); return b; }
 
-// The previous correspondence of a source point as the first candidate: (distance to it now, its index);
-// empty when there is none (index < 0) or it does not belong to the current target.
-__device__ __forceinline__ Best best_seed(const int* __restrict__ seed, size_t i, size_t nt, const float* __restrict__ tgt_xyz, double qx, double qy,
-                                          double qz) {
+// The previous correspondence of a source point as the first candidate: `seed` holds, per source point, the position
+// of that target point in the cell-sorted order (-1: none). Gives (distance to it now, its index, that position) and
+// the point itself; empty when there is none or the position does not belong to the current target.
+__device__ __forceinline__ Best best_seed(const GridView& g, const int* __restrict__ seed, size_t i, size_t nt, double qx, double qy, double qz,
+                                          float4* point = nullptr) {
     Best b;
     b.init();
     if (seed) {
-        const int j = seed[i];
-        if (j >= 0 && (size_t)j < nt) {
-            const double dx = qx - (double)tgt_xyz[3 * (size_t)j], dy = qy - (double)tgt_xyz[3 * (size_t)j + 1], dz = qz - (double)tgt_xyz[3 * (size_t)j + 2];
+        const int at = seed[i];
+        if (at >= 0 && (size_t)at < nt) {
+            const float4 t = g.pts[at];
+            const double dx = qx - (double)t.x, dy = qy - (double)t.y, dz = qz - (double)t.z;
             b.d2 = (dx * dx + dy * dy) + dz * dz;
-            b.idx = j;
+            b.idx = __float_as_int(t.w);
+            b.pos = at;
+            if (point) *point = t;
         }
     }
     return b;
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(256) void k_knn(GridView g, const double* __restric
     if (i >= n) return;
     OctK<K> b0;
     b0.init();
-    const OctK<K> b = nn_search8(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], snode, slb, s_loff, b0);
+    const OctK<K> b = nn_search8(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, b0);
     if ((threadIdx.x & 7) != 0) return;
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(256) void k_nn(GridView g, const double* __restrict
     __syncthreads();
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;   // eight lanes per query
     if (i >= n) return;
-    const Best b = nn_search8(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], snode, slb, s_loff, best_empty());
+    const Best b = nn_search8(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_empty());
     if ((threadIdx.x & 7) == 0) {
         if (idx) idx[i] = b.idx;
         if (d2) d2[i] = b.d2;
@@ -377,63 +391,332 @@ __global__ __launch_bounds__(256) void k_nn_distance(GridView g, const float* __
     __syncthreads();
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     if (i >= n) return;
-    const Best b = nn_search8(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2], snode, slb, s_loff, best_empty());
+    const Best b = nn_search8(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_empty());
     if ((threadIdx.x & 7) == 0) out[i] = (float)__dsqrt_rn(b.d2);
 }
 
 struct Mat34 { double m[12]; };
 
-// One ICP pass: p = T * [src;1] (multiply then add, k = 0..3 from a zero accumulator), nearest target
-// point q, and block-partial sums {p, q, p q^T, |p-q|^2}.
-__global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __restrict__ src, size_t n, Mat34 T,
-                                                  const float* __restrict__ tgt_xyz, size_t nt, double* __restrict__ partials,
-                                                  int* __restrict__ idx_out, int* __restrict__ seed) {
-    __shared__ unsigned snode[NN_STACK * NN_OCTETS];
-    __shared__ double slb[NN_STACK * NN_OCTETS];
-    __shared__ unsigned s_loff[MAXLEV];
-    if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
-    __syncthreads();
-    double acc[ICPX_NSUMS];
+// ---- one ICP pass, a wave per tile of 64 source points ------------------------------------------------------
+// p = T * [src;1] (multiply then add, k = 0..3 from a zero accumulator) and its nearest target point q, left in seed[]
+// as a position in the sorted target points; k_icp_sums then forms the sums {p, q, p q^T, |p-q|^2}.
+//
+// The source cloud is in Morton order, so the 64 points of a wave fall into a few neighbouring cells. The wave takes
+// the box of those cells plus one cell all round and copies the target points filed under the box into LDS (the box
+// is a set of cell columns along z, each one contiguous run of the sorted points: two reads of cell_start and one
+// run of 16-byte loads per column; TILE_CAP points at a time). Every lane then compares its query with all staged
+// points, read from LDS as broadcasts, in float: with qf = (float)q the float sum
+// s = dx^2 + dy^2 + dz^2 of float differences satisfies |q - t| >= sqrt(s) (1 - 3.1 u) - u |q|, u = 2^-24 (one
+// rounding of q, one of each difference, three of the sum), so a candidate with s above
+// thr(d) = (sqrt(d) + u (|qx| + |qy| + |qz|))^2 (1 + 2^-20), rounded up to float, is strictly farther than squared
+// distance d and cannot even tie with it. The lane keeps the smallest s, its candidate, and the second smallest s
+// (with a few low bits of s given up to carry the candidate's number, which widens the test by 2^-12);
+// the candidate's exact double distance d then shows, by thr(d), whether any other candidate could be as near
+// (hardly ever one can). What a lane finds is final when no other candidate can and it is nearer than anything
+// outside the box can be (the same test as after the 3x3x3 block of nn_search8). The other lanes (two
+// candidates too close to call in float; queries far from the cloud, as in the first passes of a badly aligned
+// start), and whole tiles whose box has more than TILE_COLS columns or TILE_MAX_PTS points, are queued for
+// k_icp_walk, which continues from the candidate they hold.
+constexpr int TILE_CAP = 512;            // points staged at a time: 8 KiB of LDS (a power of two: slots are packed into TILE_CAP - 1 bits)
+constexpr int TILE_COLS = 256;           // most columns of a box
+constexpr int TILE_MAX_PTS = 1536;       // most points of a box: a few times the usual number, so that no tile takes many times as long as the others
+
+__device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
-    for (int k = 0; k < ICPX_NSUMS; k++) acc[k] = 0.0;
-    const bool first = (threadIdx.x & 7) == 0;   // eight lanes per source point; the first one keeps the sums
-    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n; i += ((size_t)gridDim.x * blockDim.x) >> 3) {
-        const float4 s = src[i];
-        double p[3];
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            double a = 0.0;
-            a += T.m[4 * r + 0] * (double)s.x;
-            a += T.m[4 * r + 1] * (double)s.y;
-            a += T.m[4 * r + 2] * (double)s.z;
-            a += T.m[4 * r + 3];
-            p[r] = a;
-        }
-        const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, s_loff, best_seed(seed, i, nt, tgt_xyz, p[0], p[1], p[2]));
-        if (!first) continue;
-        if (seed) seed[i] = b.idx == 0x7fffffff ? -1 : b.idx;
-        if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
-        // a NaN in T leaves no candidate: read point 0 then (the sums are NaN anyway) instead of an invalid index
-        const size_t j = b.idx == 0x7fffffff ? 0 : (size_t)b.idx;
-        const double q0 = (double)tgt_xyz[3 * j], q1 = (double)tgt_xyz[3 * j + 1], q2 = (double)tgt_xyz[3 * j + 2];
-        acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
-        acc[3] += q0; acc[4] += q1; acc[5] += q2;
-        acc[6] += p[0] * q0; acc[7] += p[0] * q1; acc[8] += p[0] * q2;
-        acc[9] += p[1] * q0; acc[10] += p[1] * q1; acc[11] += p[1] * q2;
-        acc[12] += p[2] * q0; acc[13] += p[2] * q1; acc[14] += p[2] * q2;
-        acc[15] += b.d2;
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Float threshold above which a candidate's float squared distance proves it strictly farther than `best` (see above).
+__device__ __forceinline__ float prune_threshold(double best, double slack) {
+    const double r = __dsqrt_rn(best) + slack;
+    return (float)(r * r * (1.0 + 0x1p-20) * (1.0 + 0x1p-22));   // the second factor outweighs the rounding of the conversion
+}
+
+__device__ __forceinline__ void icp_transform(const Mat34& T, const float4 s, double p[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        double a = 0.0;
+        a += T.m[4 * r + 0] * (double)s.x;
+        a += T.m[4 * r + 1] * (double)s.y;
+        a += T.m[4 * r + 2] * (double)s.z;
+        a += T.m[4 * r + 3];
+        p[r] = a;
     }
-    __shared__ double sm[4][ICPX_NSUMS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+}
+
+__device__ __forceinline__ void icp_accumulate(double acc[ICPX_NSUMS], const double p[3], const float4 q, double d2) {
+    const double q0 = (double)q.x, q1 = (double)q.y, q2 = (double)q.z;
+    acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
+    acc[3] += q0; acc[4] += q1; acc[5] += q2;
+    acc[6] += p[0] * q0; acc[7] += p[0] * q1; acc[8] += p[0] * q2;
+    acc[9] += p[1] * q0; acc[10] += p[1] * q1; acc[11] += p[1] * q2;
+    acc[12] += p[2] * q0; acc[13] += p[2] * q1; acc[14] += p[2] * q2;
+    acc[15] += d2;
+}
+
+// A CU admits at most eight workgroups at a time, so single-wave workgroups would leave it at two waves per SIMD:
+// the tile kernels run TILE_WAVES independent waves per workgroup (nothing is shared between them and they never
+// meet at a workgroup barrier; inside a wave the LDS executes its instructions in order, so wave_sync only has to
+// keep the compiler from moving LDS accesses across it).
+constexpr int TILE_WAVES = 2;
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// This wave's number among all waves of the launch, and their count.
+__device__ __forceinline__ unsigned icp_wave_id() { return blockIdx.x * TILE_WAVES + (threadIdx.x >> 6); }
+
+// Sum of every accumulator over the wave, written by lane 0 as this wave's partial sums.
+__device__ __forceinline__ void icp_write_partials(double acc[ICPX_NSUMS], double* __restrict__ partials, int lane) {
 #pragma unroll
     for (int k = 0; k < ICPX_NSUMS; k++) {
         double v = acc[k];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) sm[wave][k] = v;
+        if (lane == 0) partials[(size_t)k * gridDim.x * TILE_WAVES + icp_wave_id()] = v;      // component-major: k_reduce_sums reads runs
     }
-    __syncthreads();
-    if (threadIdx.x < ICPX_NSUMS)
-        partials[(size_t)blockIdx.x * ICPX_NSUMS + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// Tile number tt of a wave. Workgroups b, b + 8, b + 16 ... run on one XCD (round-robin dispatch): the waves of such
+// a group share one contiguous run of tiles, dealt out in turn (tile tt of the group's j-th wave is number
+// tt * (waves in the group) + j of the run). Waves that are resident together then work on neighbouring tiles, whose
+// cell columns overlap, out of one L2, and a stretch of expensive tiles (long columns where the surface runs along z)
+// is spread over all waves instead of being one wave's whole share. gridDim.x is a multiple of 8.
+__device__ __forceinline__ size_t icp_tile_of(int tt, int tiles_per_wave) {
+    const size_t per_group = (size_t)(gridDim.x >> 3) * TILE_WAVES;
+    const size_t j = (size_t)(blockIdx.x >> 3) * TILE_WAVES + (threadIdx.x >> 6);
+    return (size_t)(blockIdx.x & 7u) * per_group * (size_t)tiles_per_wave + (size_t)tt * per_group + j;
+}
+
+// queue: source positions left to k_icp_walk, tile t's from entry 64 * t on, their number in qcount[t].
+// Tiles are handed out at run time (they differ several times in cost): workgroups b, b + 8, b + 16 ... run on one XCD
+// (round-robin dispatch) and such a group shares one contiguous eighth of the tiles, taken in order through one of
+// eight counters (64-bit, one cache line each, never reset: the host passes the value they had before this launch),
+// so waves that are resident together work on neighbouring tiles, whose cell columns overlap, out of one L2. One
+// counter takes about 88 additions per microsecond; an eighth of the tiles of a million points needs 2 000. seed (in / out): per source position, the position of its pair in the sorted target points.
+#ifdef ICPX_NN_STATS
+__device__ unsigned long long g_nn_stats[8];
+__device__ unsigned long long g_nn_t0[8192], g_nn_t1[8192];
+__device__ unsigned g_nn_tile_t[1 << 18], g_nn_tile_steps[1 << 18], g_nn_tile_total[1 << 18];
+#endif
+
+__global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
+                                                              int* __restrict__ idx_out, int* __restrict__ seed, size_t tiles_per_group,
+                                                              unsigned long long* __restrict__ counters, unsigned long long counter_base,
+                                                              unsigned* __restrict__ queue, unsigned* __restrict__ qcount) {
+    __shared__ float4 sw_pts[TILE_WAVES][TILE_CAP];
+    __shared__ int sw_first[TILE_WAVES][TILE_COLS];       // per column of the box: start of its run in the sorted points
+    __shared__ int sw_pre[TILE_WAVES][TILE_COLS + 4];     // ... and the number of box points in the columns before it
+    float4* const s_pts = sw_pts[threadIdx.x >> 6];
+    int* const s_first = sw_first[threadIdx.x >> 6];
+    int* const s_pre = sw_pre[threadIdx.x >> 6];
+    const int lane = (int)(threadIdx.x & 63);
+#ifdef ICPX_NN_STATS
+    if (lane == 0 && icp_wave_id() < 8192) { g_nn_t0[icp_wave_id()] = wall_clock64(); }
+#endif
+    const double h = (double)g.h, ox = (double)g.minx, oy = (double)g.miny, oz = (double)g.minz;
+    const unsigned group = blockIdx.x & 7u;
+
+    for (;;) {
+        unsigned long long taken = 0;
+        if (lane == 0) taken = atomicAdd(&counters[group * 8], 1ull) - counter_base;
+        taken = __shfl(taken, 0);
+        if (taken >= tiles_per_group) break; // uniform: every wave ends here, after at most tiles_per_group + 1 additions
+        const size_t tile = (size_t)group * tiles_per_group + taken, base = tile * 64;
+        if (base >= n) continue;             // beyond the last tile (the counter must still see tiles_per_group + 1 additions per wave)
+        const bool valid = base + lane < n;
+        const size_t i = valid ? base + lane : n - 1;    // idle lanes of the last tile shadow the last point
+#ifdef ICPX_NN_STATS
+        const unsigned long long tile_t0 = wall_clock64();
+        unsigned tile_steps = 0;
+#endif
+        const float4 s = src[i];
+        double p[3];
+        icp_transform(T, s, p);
+        Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);
+        const int cx = cell_coord((float)p[0], g.minx, g.inv, g.dx), cy = cell_coord((float)p[1], g.miny, g.inv, g.dy),
+                  cz = cell_coord((float)p[2], g.minz, g.inv, g.dz);
+        // the tile's box: its cells and one more on every side
+        const int bx0 = max(wave_min(cx) - 1, 0), bx1 = min(wave_max(cx) + 1, g.dx - 1);
+        const int by0 = max(wave_min(cy) - 1, 0), by1 = min(wave_max(cy) + 1, g.dy - 1);
+        const int bz0 = max(wave_min(cz) - 1, 0), bz1 = min(wave_max(cz) + 1, g.dz - 1);
+        const int nby = by1 - by0 + 1;
+        const long long ncols_ll = (long long)(bx1 - bx0 + 1) * nby;
+        const int ncols = (int)min(ncols_ll, (long long)TILE_COLS + 1);
+        const double margin = 1e-3 * h + 1e-6 * (fabs(p[0]) + fabs(p[1]) + fabs(p[2]));
+        // squared distance from the query to the nearest place outside the box where a target point could be (nothing
+        // lies beyond the grid's own faces)
+        double outside = INFINITY;
+        if (bx0 > 0)        { const double t = fmax(p[0] - (ox + bx0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
+        if (bx1 < g.dx - 1) { const double t = fmax(ox + (bx1 + 1) * h - p[0] - margin, 0.0); outside = fmin(outside, t * t); }
+        if (by0 > 0)        { const double t = fmax(p[1] - (oy + by0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
+        if (by1 < g.dy - 1) { const double t = fmax(oy + (by1 + 1) * h - p[1] - margin, 0.0); outside = fmin(outside, t * t); }
+        if (bz0 > 0)        { const double t = fmax(p[2] - (oz + bz0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
+        if (bz1 < g.dz - 1) { const double t = fmax(oz + (bz1 + 1) * h - p[2] - margin, 0.0); outside = fmin(outside, t * t); }
+
+        // Stage the box unless that is clearly wasted: when most lanes already hold a candidate (their previous
+        // pair) and hardly any of those is near enough for the box to settle the query.
+        const int seeded = __popcll(__ballot(b.pos >= 0)), promising = __popcll(__ballot(b.pos >= 0 && outside > b.d2));
+        bool staged = ncols <= TILE_COLS && !(seeded >= 32 && promising < 8);
+        int total = 0;
+#ifdef ICPX_NN_STATS
+        if (lane == 0) { atomicAdd(&g_nn_stats[0], 1ull); atomicAdd(&g_nn_stats[6], (unsigned long long)ncols); }
+#endif
+        wave_sync();                     // the previous tile is done with the column tables
+        if (staged) {
+            for (int c0 = 0; c0 < ncols; c0 += 64) {
+                const int c = c0 + lane;
+                int first = 0, cnt = 0;
+                if (c < ncols) {
+                    const size_t cbase = ((size_t)(bx0 + c / nby) * g.dy + (by0 + c % nby)) * g.dz;
+                    first = g.start[cbase + bz0];
+                    cnt = g.start[cbase + bz1 + 1] - first;
+                }
+                int pre = cnt;               // inclusive prefix sum over the lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o); if (lane >= o) pre += v; }
+                if (c < ncols) { s_first[c] = first; s_pre[c] = total + pre - cnt; }
+                total += __shfl(pre, 63);
+            }
+            if (lane == 0) s_pre[ncols] = total;
+            staged = total <= TILE_MAX_PTS;
+#ifdef ICPX_NN_STATS
+            if (lane == 0) { atomicAdd(&g_nn_stats[1], staged ? 1ull : 0ull); atomicAdd(&g_nn_stats[7], (unsigned long long)total); }
+#endif
+        }
+        bool ambiguous = false;
+        if (staged) {
+            // A branch-free float pass over the box's points, every lane against every point (read from LDS as
+            // broadcasts). The low bits (TILE_CAP - 1) of every float squared distance are replaced by the point's slot
+            // in the staging area (kept in the staged point's fourth word), so the smallest such word, u1, names its
+            // candidate; u2 is the second smallest. Distances are not negative, so the words order like the values.
+            const float qfx = (float)p[0], qfy = (float)p[1], qfz = (float)p[2];
+            unsigned u1 = 0x7f800000u, u2 = 0x7f800000u;          // +infinity
+            int vlo = 0;                     // first list position of the part of the box u1 was found in
+            const int sub = lane & 7;
+            for (int lo = 0; lo < total; lo += TILE_CAP) {
+                const int hi = min(lo + TILE_CAP, total), m = hi - lo;
+                wave_sync();                 // column tables written / the previous part has been compared
+                // eight lanes copy one column at a time (consecutive lanes, consecutive points): its part inside [lo, hi)
+                for (int c = lane >> 3; c < ncols; c += 8) {
+                    const int at = s_pre[c], end = s_pre[c + 1];
+                    if (end <= lo || at >= hi) continue;
+                    const int first = s_first[c];
+                    for (int v = max(at, lo) + sub; v < min(end, hi); v += 8) {
+                        float4 t = g.pts[first + (v - at)];
+                        t.w = __int_as_float(v - lo);
+                        s_pts[v - lo] = t;
+                    }
+                }
+                wave_sync();
+#ifdef ICPX_NN_STATS
+                tile_steps += m;
+#endif
+                const unsigned before = u1;
+#pragma unroll 8
+                for (int k = 0; k < m; k++) {
+                    const float4 t = s_pts[k];
+                    const float dx = qfx - t.x, dy = qfy - t.y, dz = qfz - t.z;
+                    const float sq = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    const unsigned u = (__float_as_uint(sq) & ~(unsigned)(TILE_CAP - 1)) | __float_as_uint(t.w);
+                    u2 = min(max(u, u1), u2);               // u1 <= u2: the middle one of the three is the new second smallest
+                    u1 = min(u1, u);
+                }
+                if (u1 != before) vlo = lo;
+            }
+            // Then the exact distance of that one candidate. It is the nearest of the box's points, alone, unless
+            // another one's float distance is within the rounding slack of it (see prune_threshold; the slot bits add
+            // 2^-14 each way): about one lane in a few thousand, which is left to the walk, with this candidate to start from.
+            if (u1 < 0x7f800000u) {
+                const int vbest = vlo + (int)(u1 & (unsigned)(TILE_CAP - 1));
+                int c = 0, hi = ncols - 1;   // the candidate's column: the last one that starts at or before it
+                while (c < hi) { const int mid = (c + hi + 1) >> 1; if (s_pre[mid] <= vbest) c = mid; else hi = mid - 1; }
+                const int at = s_first[c] + (vbest - s_pre[c]);
+                const float4 t = g.pts[at];
+                const double ex = p[0] - (double)t.x, ey = p[1] - (double)t.y, ez = p[2] - (double)t.z;
+                const double d = (ex * ex + ey * ey) + ez * ez;
+                const float thr = prune_threshold(d, 0x1.000002p-24 * (fabs(p[0]) + fabs(p[1]) + fabs(p[2])));
+                ambiguous = !(__uint_as_float(u2) > thr * (1.0f + 0x1p-12f));
+                b.offer(d, __float_as_int(t.w), at);
+            }
+        }
+        const bool settled = staged && !ambiguous && outside > b.d2;
+#ifdef ICPX_NN_STATS
+        if (lane == 0 && tile < (1u << 18)) { g_nn_tile_t[tile] = (unsigned)(wall_clock64() - tile_t0); g_nn_tile_steps[tile] = tile_steps; g_nn_tile_total[tile] = (unsigned)total; }
+#endif
+        const unsigned long long pend = __ballot(valid && !settled);
+        if ((pend >> lane) & 1ull) queue[base + __popcll(pend & ((1ull << lane) - 1ull))] = (unsigned)i;
+        if (lane == 0) qcount[tile] = (unsigned)__popcll(pend);
+        if (!valid) continue;
+        seed[i] = b.pos;                     // for a queued lane: the candidate its walk starts from
+        if (settled && idx_out) idx_out[__float_as_int(s.w)] = b.idx;
+    }
+#ifdef ICPX_NN_STATS
+    if (lane == 0 && icp_wave_id() < 8192) g_nn_t1[icp_wave_id()] = wall_clock64();
+#endif
+}
+
+// The queued source points: eight lanes each, the pyramid walk of nn_search8 from the candidate in seed[]. Tile t's
+// entries start at queue[64 * t], qcount[t] of them; a workgroup takes tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+__global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __restrict__ src, Mat34 T, size_t nt, const unsigned* __restrict__ queue,
+                                                  const unsigned* __restrict__ qcount, size_t ntiles, int* __restrict__ idx_out,
+                                                  int* __restrict__ seed) {
+    __shared__ unsigned snode[NN_STACK * NN_OCTETS];
+    __shared__ double slb[NN_STACK * NN_OCTETS];
+    __shared__ unsigned s_loff[MAXLEV];
+    __shared__ unsigned s_count[256];
+    if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
+    for (size_t r0 = blockIdx.x; r0 < ntiles; r0 += (size_t)gridDim.x * 256) {
+        // the counts of this workgroup's next 256 tiles at once, instead of one dependent load per tile
+        __syncthreads();
+        const size_t mine = r0 + (size_t)threadIdx.x * gridDim.x;
+        s_count[threadIdx.x] = mine < ntiles ? qcount[mine] : 0u;
+        __syncthreads();
+        for (int k = 0; k < 256; k++) {
+            const unsigned count = s_count[k];
+            if (count == 0) continue;
+            const size_t r = r0 + (size_t)k * gridDim.x;
+            for (unsigned e = threadIdx.x >> 3; e < count; e += NN_OCTETS) {
+                const size_t i = queue[r * 64 + e];
+                const float4 s = src[i];
+                double p[3];
+                icp_transform(T, s, p);
+                const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(g, seed, i, nt, p[0], p[1], p[2]));
+                if ((threadIdx.x & 7) != 0) continue;
+                seed[i] = b.pos;
+                if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
+            }
+        }
+    }
+}
+
+// Block-partial sums {p, q, p q^T, |p-q|^2} over the pairs in seed[]: lane l of a block adds the terms of point l of
+// its tiles in tile order and the lanes are summed by a fixed butterfly, so the sums depend on the pairs alone (not on
+// which points were settled by k_icp_tile and which by the walk, which varies with the previous pass).
+__global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_sums(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
+                                                 const int* __restrict__ seed, int tiles_per_block, double* __restrict__ partials) {
+    const int lane = (int)(threadIdx.x & 63);
+    double acc[ICPX_NSUMS];
+#pragma unroll
+    for (int k = 0; k < ICPX_NSUMS; k++) acc[k] = 0.0;
+    for (int tt = 0; tt < tiles_per_block; tt++) {
+        const size_t i = icp_tile_of(tt, tiles_per_block) * 64 + lane;
+        if (i >= n) continue;
+        double p[3];
+        icp_transform(T, src[i], p);
+        const int at = seed[i];
+        // no candidate at all (a NaN in T): the sums are NaN anyway
+        const float4 q = at >= 0 && (size_t)at < nt ? g.pts[at] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const double dx = p[0] - (double)q.x, dy = p[1] - (double)q.y, dz = p[2] - (double)q.z;
+        icp_accumulate(acc, p, q, (dx * dx + dy * dy) + dz * dz);
+    }
+    icp_write_partials(acc, partials, lane);
 }
 
 // Trimmed ICP pass, first half: p = T * [src;1] and its nearest target point for every source point, stored
@@ -441,8 +724,7 @@ __global__ __launch_bounds__(256) void k_icp_step(GridView g, const float4* __re
 // order like the value), o itself as the sort value, p and the correspondence.
 __global__ __launch_bounds__(256) void k_icp_pairs(GridView g, const float4* __restrict__ src, size_t n, Mat34 T,
                                                    unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
-                                                   double* __restrict__ pbuf, int* __restrict__ idx, const float* __restrict__ tgt_xyz, size_t nt,
-                                                   int* __restrict__ seed) {
+                                                   double* __restrict__ pbuf, int* __restrict__ idx, size_t nt, int* __restrict__ seed) {
     __shared__ unsigned snode[NN_STACK * NN_OCTETS];
     __shared__ double slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
@@ -461,9 +743,9 @@ __global__ __launch_bounds__(256) void k_icp_pairs(GridView g, const float4* __r
         a += T.m[4 * r + 3];
         p[r] = a;
     }
-    const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, s_loff, best_seed(seed, i, nt, tgt_xyz, p[0], p[1], p[2]));
+    const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(g, seed, i, nt, p[0], p[1], p[2]));
     if ((threadIdx.x & 7) != 0) return;
-    if (seed) seed[i] = b.idx == 0x7fffffff ? -1 : b.idx;
+    if (seed) seed[i] = b.pos;
     const size_t o = (size_t)__float_as_int(s.w);
     keys[o] = (unsigned long long)__double_as_longlong(b.d2);
     vals[o] = (unsigned)o;
@@ -482,7 +764,7 @@ __global__ __launch_bounds__(256) void k_icp_trim_sums(const unsigned* __restric
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < keep; r += (size_t)gridDim.x * blockDim.x) {
         const size_t o = order[r];
         const double p0 = pbuf[3 * o], p1 = pbuf[3 * o + 1], p2 = pbuf[3 * o + 2];
-        const size_t j = idx[o] == 0x7fffffff ? 0 : (size_t)idx[o];   // no candidate (NaN transform): see k_icp_step
+        const size_t j = idx[o] == 0x7fffffff ? 0 : (size_t)idx[o];   // no candidate (NaN transform): see k_icp_tile
         const double q0 = (double)tgt_xyz[3 * j], q1 = (double)tgt_xyz[3 * j + 1], q2 = (double)tgt_xyz[3 * j + 2];
         acc[0] += p0; acc[1] += p1; acc[2] += p2;
         acc[3] += q0; acc[4] += q1; acc[5] += q2;
@@ -501,22 +783,23 @@ __global__ __launch_bounds__(256) void k_icp_trim_sums(const unsigned* __restric
     }
     __syncthreads();
     if (threadIdx.x < ICPX_NSUMS)
-        partials[(size_t)blockIdx.x * ICPX_NSUMS + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
-// Fixed-order final reduction of the block partials: thread t sums component t%16 of blocks t/16, t/16+64, ...
-__global__ __launch_bounds__(1024) void k_reduce_sums(const double* __restrict__ partials, int nblocks, double* __restrict__ sums) {
-    __shared__ double sm[1024];
-    const int comp = threadIdx.x & 15, lanegrp = threadIdx.x >> 4;
+// Fixed-order final reduction of the block partials (component-major: partials[component * nblocks + block]): one
+// workgroup per component, thread t adds blocks t, t + 256, ... in that order, then a tree over the threads.
+__global__ __launch_bounds__(256) void k_reduce_sums(const double* __restrict__ partials, int nblocks, double* __restrict__ sums) {
+    __shared__ double sm[256];
+    const double* row = partials + (size_t)blockIdx.x * nblocks;
     double v = 0.0;
-    for (int b = lanegrp; b < nblocks; b += 64) v += partials[(size_t)b * ICPX_NSUMS + comp];
+    for (int b = threadIdx.x; b < nblocks; b += 256) v += row[b];
     sm[threadIdx.x] = v;
     __syncthreads();
-    for (int s = 32; s > 0; s >>= 1) {
-        if (lanegrp < s) sm[threadIdx.x] += sm[threadIdx.x + s * 16];
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x < ICPX_NSUMS) sums[threadIdx.x] = sm[threadIdx.x];
+    if (threadIdx.x == 0) sums[blockIdx.x] = sm[0];
 }
 
 GridView view_of(const icpx_ctx* ctx) {
@@ -524,7 +807,7 @@ GridView view_of(const icpx_ctx* ctx) {
     g.dx = ctx->gdim[0]; g.dy = ctx->gdim[1]; g.dz = ctx->gdim[2];
     g.minx = ctx->gmin[0]; g.miny = ctx->gmin[1]; g.minz = ctx->gmin[2];
     g.h = ctx->gh; g.inv = ctx->ginv;
-    g.range = ctx->cell_range.as<int2>();
+    g.start = ctx->cell_start.as<int>();
     g.pts = ctx->sorted_pts.as<float4>();
     g.masks = ctx->pyr_masks.as<unsigned char>();
     g.loff = ctx->pyr_tab.as<unsigned>();
@@ -566,8 +849,9 @@ int icpx_grid_build(icpx_ctx* ctx) {
         ctx->gh = (float)h; ctx->ginv = 1.0f / ctx->gh;
         for (int c = 0; c < 3; c++) { ctx->gdim[c] = dim[c]; ctx->gmin[c] = ctx->bbmin[c]; }
         const size_t ncells = (size_t)dim[0] * dim[1] * dim[2];
-        ICPX_TRY(icpx_reserve(ctx, ctx->cell_range, ncells * sizeof(int2)));
-        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->cell_range.p, 0, ncells * sizeof(int2), ctx->stream));
+        ICPX_TRY(icpx_reserve(ctx, ctx->cell_start, (ncells + 1) * sizeof(int)));
+        ICPX_TRY(icpx_reserve(ctx, ctx->cell_count, (ncells + 1) * sizeof(int)));
+        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->cell_count.p, 0, (ncells + 1) * sizeof(int), ctx->stream));
         unsigned* distinct = reinterpret_cast<unsigned*>(ctx->edt_counters.as<unsigned long long>() + 3);
         ICPX_CHECK_HIP(ctx, hipMemsetAsync(distinct, 0, sizeof(unsigned), ctx->stream));
         GridView g = view_of(ctx);
@@ -577,9 +861,17 @@ int icpx_grid_build(icpx_ctx* ctx) {
         unsigned bits = 1;
         while ((1ull << bits) < ncells) bits++;
         ICPX_TRY(icpx_sort_pairs(ctx, n, bits));
-        hipLaunchKernelGGL(k_cell_ranges, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sort_keys_b.as<unsigned>(), n,
-                           ctx->cell_range.as<int2>(), distinct);
-        ICPX_TRY(icpx_launch_check(ctx, "k_cell_ranges"));
+        hipLaunchKernelGGL(k_cell_counts, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sort_keys_b.as<unsigned>(), n,
+                           ctx->cell_count.as<int>(), distinct);
+        ICPX_TRY(icpx_launch_check(ctx, "k_cell_counts"));
+        {   // cell_start = exclusive prefix sum of the counts (the entry behind the last cell is the number of points)
+            size_t tmp = 0;
+            ICPX_CHECK_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, ctx->cell_count.as<int>(), ctx->cell_start.as<int>(), 0, ncells + 1,
+                                                        rocprim::plus<int>(), ctx->stream));
+            ICPX_TRY(icpx_reserve(ctx, ctx->sort_tmp, tmp));
+            ICPX_CHECK_HIP(ctx, rocprim::exclusive_scan(ctx->sort_tmp.p, tmp, ctx->cell_count.as<int>(), ctx->cell_start.as<int>(), 0, ncells + 1,
+                                                        rocprim::plus<int>(), ctx->stream));
+        }
         unsigned occupied = 0;
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(&occupied, distinct, sizeof occupied, hipMemcpyDeviceToHost, ctx->stream));
         ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -616,7 +908,7 @@ int icpx_grid_build(icpx_ctx* ctx) {
             const unsigned nb = (unsigned)((cells + 255) / 256);
             unsigned* upw = reinterpret_cast<unsigned*>(fl + ctx->pyr_off[l]);
             if (l == 1)
-                hipLaunchKernelGGL(k_pyr_from_cells, dim3(nb), dim3(256), 0, ctx->stream, ctx->cell_range.as<int2>(), lo[0], lo[1], lo[2], upw, up[1], up[2]);
+                hipLaunchKernelGGL(k_pyr_from_cells, dim3(nb), dim3(256), 0, ctx->stream, ctx->cell_start.as<int>(), lo[0], lo[1], lo[2], upw, up[1], up[2]);
             else
                 hipLaunchKernelGGL(k_pyr_from_masks, dim3(nb), dim3(256), 0, ctx->stream, fl + ctx->pyr_off[l - 1], lo[0], lo[1], lo[2], upw, up[1], up[2]);
         }
@@ -722,14 +1014,64 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     if (!ctx->grid_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_step: no target cloud (call icpx_set_target first)");
     if (ctx->ns == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_step: no source cloud (call icpx_set_source first)");
     if (!T) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_step: T is NULL");
-    const int blocks = (int)std::min<size_t>((ctx->ns + 31) / 32, (size_t)ctx->num_cus * 32);   // 32 source points per block
-    ICPX_TRY(icpx_reserve(ctx, ctx->partials, (size_t)blocks * ICPX_NSUMS * sizeof(double)));
+    // One wave per tile of 64 source points, TILE_WAVES waves per workgroup; 7 workgroups of the tile kernel fit a CU
+    // (LDS). The workgroup counts are multiples of 8 (one share of the tiles per XCD).
+    const size_t tiles = (ctx->ns + 63) / 64;
+    const int blocks = (int)((std::min<size_t>((tiles + TILE_WAVES - 1) / TILE_WAVES, (size_t)ctx->num_cus * 7) + 7) / 8 * 8);
+    const size_t tiles_per_group = (tiles + 7) / 8;
+    const int sblocks = (int)((std::min<size_t>((tiles + TILE_WAVES - 1) / TILE_WAVES, (size_t)ctx->num_cus * 8) + 7) / 8 * 8);
+    const int swaves = sblocks * TILE_WAVES;
+    const int tiles_per_sblock = (int)((tiles + swaves - 1) / swaves);
+    ICPX_TRY(icpx_reserve(ctx, ctx->partials, (size_t)swaves * ICPX_NSUMS * sizeof(double)));
+    // the eight tile counters (64 B apart), the per-tile counts of queued points, the queue (64 entries per tile)
+    if (!ctx->tile_counters.p) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->tile_counters, 8 * 64));
+        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->tile_counters.p, 0, 8 * 64, ctx->stream));
+        ctx->tile_counter_base = 0;
+    }
+    ICPX_TRY(icpx_reserve(ctx, ctx->walk_queue, (tiles + tiles * 64) * sizeof(unsigned)));
+    unsigned* qcount = ctx->walk_queue.as<unsigned>();
+    unsigned* queue = qcount + tiles;
+    // every wave of a group adds once more than it gets tiles, and the group's tiles are added for once each
+    const unsigned long long counter_base = ctx->tile_counter_base;
+    ctx->tile_counter_base += tiles_per_group + (unsigned long long)(blocks / 8) * TILE_WAVES;
     Mat34 M;
     for (int k = 0; k < 12; k++) M.m[k] = T[k];
-    hipLaunchKernelGGL(k_icp_step, dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), ctx->src_pts.as<float4>(), ctx->ns, M,
-                       ctx->tgt_xyz.as<float>(), ctx->nt, ctx->partials.as<double>(), idx_dev, ctx->nn_seed.as<int>());
-    hipLaunchKernelGGL(k_reduce_sums, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, sums_dev);
-    return icpx_launch_check(ctx, "k_icp_step");
+    const GridView g = view_of(ctx);
+    double* part = ctx->partials.as<double>();
+    hipLaunchKernelGGL(k_icp_tile, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
+                       ctx->nn_seed.as<int>(), tiles_per_group, ctx->tile_counters.as<unsigned long long>(), counter_base, queue, qcount);
+    hipLaunchKernelGGL(k_icp_walk, dim3((unsigned)std::min<size_t>(tiles, (size_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, g,
+                       ctx->src_pts.as<float4>(), M, ctx->nt, queue, qcount, tiles, idx_dev, ctx->nn_seed.as<int>());
+    hipLaunchKernelGGL(k_icp_sums, dim3(sblocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt,
+                       ctx->nn_seed.as<int>(), tiles_per_sblock, part);
+    hipLaunchKernelGGL(k_reduce_sums, dim3(ICPX_NSUMS), dim3(256), 0, ctx->stream, part, swaves, sums_dev);
+#ifdef ICPX_NN_STATS
+    {
+        unsigned long long h[8];
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nn_stats), sizeof h);
+        fprintf(stderr, "tiles %llu staged %llu cols/tile %.1f pts/staged tile %.1f\n", h[0], h[1], (double)h[6] / h[0], (double)h[7] / (h[1] ? h[1] : 1));
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof z);
+        static std::vector<unsigned long long> t0(8192), t1(8192);
+        hipMemcpyFromSymbol(t0.data(), HIP_SYMBOL(g_nn_t0), 8192 * 8);
+        hipMemcpyFromSymbol(t1.data(), HIP_SYMBOL(g_nn_t1), 8192 * 8);
+        unsigned long long lo = ~0ull, hi = 0, latest_start = 0; double sum = 0, mx = 0;
+        for (int b = 0; b < blocks * TILE_WAVES && b < 8192; b++) { lo = std::min(lo, t0[b]); hi = std::max(hi, t1[b]); latest_start = std::max(latest_start, t0[b]); sum += (double)(t1[b] - t0[b]); mx = std::max(mx, (double)(t1[b] - t0[b])); }
+        fprintf(stderr, "   waves %d: span %.1f us, mean wave %.1f us, longest %.1f us, last start at %.1f us\n", blocks * TILE_WAVES, (hi - lo) / 100.0, sum / (blocks * TILE_WAVES) / 100.0, mx / 100.0, (latest_start - lo) / 100.0);
+        const size_t nt_ = std::min<size_t>(tiles, 1u << 18);
+        static std::vector<unsigned> tt(1 << 18), ts(1 << 18), tp(1 << 18);
+        hipMemcpyFromSymbol(tt.data(), HIP_SYMBOL(g_nn_tile_t), nt_ * 4); hipMemcpyFromSymbol(ts.data(), HIP_SYMBOL(g_nn_tile_steps), nt_ * 4); hipMemcpyFromSymbol(tp.data(), HIP_SYMBOL(g_nn_tile_total), nt_ * 4);
+        std::vector<size_t> ord(nt_); for (size_t k = 0; k < nt_; k++) ord[k] = k;
+        std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return tt[a] > tt[b]; });
+        double tsum = 0, ssum = 0; for (size_t k = 0; k < nt_; k++) { tsum += tt[k]; ssum += ts[k]; }
+        fprintf(stderr, "   tile time: mean %.2f us, median %.2f, p99 %.2f, max %.2f; mean steps %.1f; slowest:", tsum / nt_ / 100.0, tt[ord[nt_ / 2]] / 100.0, tt[ord[nt_ / 100]] / 100.0, tt[ord[0]] / 100.0, ssum / nt_);
+        for (int k = 0; k < 5; k++) fprintf(stderr, " [t %.1f us steps %u pts %u]", tt[ord[k]] / 100.0, ts[ord[k]], tp[ord[k]]);
+        fprintf(stderr, "\n");
+    }
+#endif
+    return icpx_launch_check(ctx, "k_icp_tile");
 }
 
 extern "C" int icpx_icp_step(icpx_ctx* ctx, const double T[16], double sums[ICPX_NSUMS], int32_t* idx_opt, int idx_where) {
@@ -775,14 +1117,14 @@ extern "C" int icpx_icp_step_trimmed(icpx_ctx* ctx, const double T[16], uint64_t
     for (int k = 0; k < 12; k++) M.m[k] = T[k];
     hipLaunchKernelGGL(k_icp_pairs, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, ctx->stream, view_of(ctx), ctx->src_pts.as<float4>(), n, M,
                        ctx->trim_keys_a.as<unsigned long long>(), ctx->trim_vals_a.as<unsigned>(), ctx->trim_p.as<double>(),
-                       ctx->trim_idx.as<int>(), ctx->tgt_xyz.as<float>(), ctx->nt, ctx->nn_seed.as<int>());
+                       ctx->trim_idx.as<int>(), ctx->nt, ctx->nn_seed.as<int>());
     ICPX_TRY(icpx_launch_check(ctx, "k_icp_pairs"));
     ICPX_TRY(icpx_sort_pairs64(ctx, n, ctx->trim_keys_a.as<unsigned long long>(), ctx->trim_keys_b.as<unsigned long long>(),
                                ctx->trim_vals_a.as<unsigned>(), ctx->trim_vals_b.as<unsigned>()));
     hipLaunchKernelGGL(k_icp_trim_sums, dim3(blocks), dim3(256), 0, ctx->stream, ctx->trim_vals_b.as<unsigned>(),
                        ctx->trim_keys_b.as<unsigned long long>(), (size_t)keep, ctx->trim_p.as<double>(), ctx->trim_idx.as<int>(),
                        ctx->tgt_xyz.as<float>(), ctx->partials.as<double>());
-    hipLaunchKernelGGL(k_reduce_sums, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.as<double>(), blocks, ctx->sums.as<double>());
+    hipLaunchKernelGGL(k_reduce_sums, dim3(ICPX_NSUMS), dim3(256), 0, ctx->stream, ctx->partials.as<double>(), blocks, ctx->sums.as<double>());
     ICPX_TRY(icpx_launch_check(ctx, "k_icp_trim_sums"));
     ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sums, ctx->sums.p, ICPX_NSUMS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -66,3 +66,56 @@ def test_icp_step_trimmed(gpu_ctx, oracle, bunny000, bunny045):
     from icp_amd import IcpxError
     with pytest.raises(IcpxError):
         gpu_ctx.icp_step_trimmed(T, n + 1)
+
+
+def _transform(src, T):
+    """T * [src; 1] in double with the kernel's operation order: products added to a zero accumulator, k = 0..3."""
+    s = src.astype(np.float64)
+    out = np.empty_like(s)
+    for r in range(3):
+        out[:, r] = ((0.0 + T[r, 0] * s[:, 0]) + T[r, 1] * s[:, 1]) + T[r, 2] * s[:, 2] + T[r, 3]
+    return out
+
+
+def _check_step(ctx, O, src, tgt, T, rng, nsample):
+    sums, idx = ctx.icp_step(T, want_idx=True)
+    p = _transform(src, T)
+    pick = rng.choice(src.shape[0], nsample, replace=False)
+    ridx, rd2 = O.nn_brute(np.ascontiguousarray(p[pick]), tgt)
+    assert np.array_equal(idx[pick], ridx)                      # exact pairs, lowest index among equals
+    assert idx.min() >= 0 and idx.max() < tgt.shape[0]
+    q = tgt[idx].astype(np.float64)
+    d = p - q
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    assert np.array_equal(d2[pick], rd2)
+    want = np.concatenate([p.sum(0), q.sum(0), (p.T @ q).reshape(9), [d2.sum()]])
+    np.testing.assert_allclose(sums, want, rtol=1e-12, atol=1e-12)
+    return sums
+
+
+def test_icp_step_million_by_million(oracle):
+    """The fused pass on the synthetic 1 M x 1 M pair (source 10 degrees off the target): first from scratch with the
+    queries far from the surface, then two passes near alignment that start from the previous pairs — sampled pairs
+    against brute force, and the 16 sums against a double-precision recomputation from all returned pairs."""
+    from conftest import synth_surface
+    from icp_amd.api import Context
+    n = 1_000_000
+    tgt = synth_surface(n, 42)
+    Tm = rigid([1, 1, 1], 10.0, [0.02, -0.01, 0.015])
+    src = (synth_surface(n, 43, noise=1e-3).astype(np.float64) @ Tm[:3, :3].T + Tm[:3, 3]).astype(np.float32)
+    rng = np.random.default_rng(12)
+    ctx = Context(0)
+    try:
+        ctx.set_target(tgt)
+        ctx.set_source(src)
+        s0 = _check_step(ctx, oracle, src, tgt, np.eye(4), rng, 3000)
+        back = np.linalg.inv(Tm)
+        s1 = _check_step(ctx, oracle, src, tgt, back, rng, 3000)
+        assert s1[15] < 0.01 * s0[15]
+        nudge = rigid([0, 0, 1], 0.05, [1e-4, 0, -1e-4]) @ back
+        _check_step(ctx, oracle, src, tgt, nudge, rng, 3000)
+        # the same pass twice gives the same bits (fixed reduction order), whatever the previous pairs were
+        a = ctx.icp_step(nudge); b = ctx.icp_step(nudge)
+        assert np.array_equal(a, b)
+    finally:
+        ctx.close()
