@@ -52,7 +52,7 @@ struct icpx_ctx {
     DevBuf nn_seed;          // ns int, by sorted source position: position in sorted_pts of the target point the source point was paired with by the last ICP pass, -1 = none
     DevBuf tile_counters;    // eight 64-bit counters, 64 B apart, that hand out the tiles of an ICP pass; never reset
     unsigned long long tile_counter_base = 0;   // their common value before the next launch
-    DevBuf walk_queue;       // one ICP pass: per tile of 64 source points the number it left to the pyramid walk, then those points' positions (64 entries per tile)
+    DevBuf walk_queue;       // one ICP pass: the source points left to the pyramid walk, in 64 parts: a counter per part (16 words apart, zero between passes), then the parts' entries
     DevBuf partials;         // per-block partial sums
     DevBuf sums;             // ICPX_NSUMS doubles
     DevBuf scratch_q, scratch_idx, scratch_d2, scratch_f;   // staging for host-pointer calls

@@ -494,7 +494,10 @@ __device__ __forceinline__ size_t icp_tile_of(int tt, int tiles_per_wave) {
     return (size_t)(blockIdx.x & 7u) * per_group * (size_t)tiles_per_wave + (size_t)tt * per_group + j;
 }
 
-// queue: source positions left to k_icp_walk, tile t's from entry 64 * t on, their number in qcount[t].
+// queue: source positions left to k_icp_walk, in WALK_SHARDS parts: the tiles are cut into that many contiguous runs of
+// tiles_per_shard, run r appends to the part that starts at entry 64 * tiles_per_shard * r and counts in qcount[16 * r]
+// (zero before the launch; k_reduce_sums clears them for the next pass). With one counter for all, every tile's
+// addition would queue at one word, which takes about 88 of them per microsecond.
 // Tiles are handed out at run time (they differ several times in cost): workgroups b, b + 8, b + 16 ... run on one XCD
 // (round-robin dispatch) and such a group shares one contiguous eighth of the tiles, taken in order through one of
 // eight counters (64-bit, one cache line each, never reset: the host passes the value they had before this launch),
@@ -509,11 +512,14 @@ __device__ unsigned g_nn_tile_t[1 << 18], g_nn_tile_steps[1 << 18], g_nn_tile_to
 __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
                                                               int* __restrict__ idx_out, int* __restrict__ seed, size_t tiles_per_group,
                                                               unsigned long long* __restrict__ counters, unsigned long long counter_base,
-                                                              unsigned* __restrict__ queue, unsigned* __restrict__ qcount) {
-    __shared__ float4 sw_pts[TILE_WAVES][TILE_CAP];
+                                                              unsigned* __restrict__ queue, unsigned* __restrict__ qcount, unsigned tiles_per_shard) {
+    __shared__ float4 sw_pts[TILE_WAVES][TILE_CAP + 8];         // as four arrays of TILE_CAP words: x, y, z, slot number
     __shared__ int sw_first[TILE_WAVES][TILE_COLS];       // per column of the box: start of its run in the sorted points
     __shared__ int sw_pre[TILE_WAVES][TILE_COLS + 4];     // ... and the number of box points in the columns before it
-    float4* const s_pts = sw_pts[threadIdx.x >> 6];
+    float* const s_x = reinterpret_cast<float*>(sw_pts[threadIdx.x >> 6]);
+    float* const s_y = s_x + TILE_CAP + 8;   // room for the padding of the last group
+    float* const s_z = s_y + TILE_CAP + 8;
+    float* const s_w = s_z + TILE_CAP + 8;
     int* const s_first = sw_first[threadIdx.x >> 6];
     int* const s_pre = sw_pre[threadIdx.x >> 6];
     const int lane = (int)(threadIdx.x & 63);
@@ -593,10 +599,12 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         bool ambiguous = false;
         if (staged) {
             // A branch-free float pass over the box's points, every lane against every point (read from LDS as
-            // broadcasts). The low bits (TILE_CAP - 1) of every float squared distance are replaced by the point's slot
-            // in the staging area (kept in the staged point's fourth word), so the smallest such word, u1, names its
-            // candidate; u2 is the second smallest. Distances are not negative, so the words order like the values.
-            const float qfx = (float)p[0], qfy = (float)p[1], qfz = (float)p[2];
+            // broadcasts, four points per read and coordinate; two points per packed float instruction). The low bits
+            // (TILE_CAP - 1) of every float squared distance are replaced by the point's slot in the staging area, so
+            // the smallest such word, u1, names its candidate; u2 is the second smallest. Distances are not negative,
+            // so the words order like the values.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 qx2 = {(float)p[0], (float)p[0]}, qy2 = {(float)p[1], (float)p[1]}, qz2 = {(float)p[2], (float)p[2]};
             unsigned u1 = 0x7f800000u, u2 = 0x7f800000u;          // +infinity
             int vlo = 0;                     // first list position of the part of the box u1 was found in
             const int sub = lane & 7;
@@ -609,24 +617,41 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
                     if (end <= lo || at >= hi) continue;
                     const int first = s_first[c];
                     for (int v = max(at, lo) + sub; v < min(end, hi); v += 8) {
-                        float4 t = g.pts[first + (v - at)];
-                        t.w = __int_as_float(v - lo);
-                        s_pts[v - lo] = t;
+                        const float4 t = g.pts[first + (v - at)];
+                        s_x[v - lo] = t.x; s_y[v - lo] = t.y; s_z[v - lo] = t.z; s_w[v - lo] = __int_as_float(v - lo);
                     }
                 }
+                // up to seven far-away points fill the last group of eight
+                if (lane < ((8 - (m & 7)) & 7)) { s_x[m + lane] = 3e18f; s_y[m + lane] = 3e18f; s_z[m + lane] = 3e18f; s_w[m + lane] = __int_as_float(m + lane); }
                 wave_sync();
 #ifdef ICPX_NN_STATS
                 tile_steps += m;
 #endif
                 const unsigned before = u1;
-#pragma unroll 8
-                for (int k = 0; k < m; k++) {
-                    const float4 t = s_pts[k];
-                    const float dx = qfx - t.x, dy = qfy - t.y, dz = qfz - t.z;
-                    const float sq = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    const unsigned u = (__float_as_uint(sq) & ~(unsigned)(TILE_CAP - 1)) | __float_as_uint(t.w);
-                    u2 = min(max(u, u1), u2);               // u1 <= u2: the middle one of the three is the new second smallest
-                    u1 = min(u1, u);
+                const unsigned keep = ~(unsigned)(TILE_CAP - 1);
+                // the two smallest of {u1 <= u2, a, b}
+                auto take2 = [&](unsigned a, unsigned b) {
+                    const unsigned lo2 = min(a, b), hi2 = max(a, b), c = min(u2, hi2);
+                    unsigned mid;
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(mid) : "v"(u1), "v"(lo2), "v"(c));   // c >= min(u1, lo2): the second smallest of the four
+                    u2 = mid;
+                    u1 = min(u1, lo2);
+                };
+                auto four = [&](const float4 X, const float4 Y, const float4 Z, const float4 W) {
+                    const f2 dxa = qx2 - f2{X.x, X.y}, dya = qy2 - f2{Y.x, Y.y}, dza = qz2 - f2{Z.x, Z.y};
+                    const f2 dxb = qx2 - f2{X.z, X.w}, dyb = qy2 - f2{Y.z, Y.w}, dzb = qz2 - f2{Z.z, Z.w};
+                    const f2 sa = __builtin_elementwise_fma(dza, dza, __builtin_elementwise_fma(dya, dya, dxa * dxa));
+                    const f2 sb = __builtin_elementwise_fma(dzb, dzb, __builtin_elementwise_fma(dyb, dyb, dxb * dxb));
+                    take2((__float_as_uint(sa.x) & keep) | __float_as_uint(W.x), (__float_as_uint(sa.y) & keep) | __float_as_uint(W.y));
+                    take2((__float_as_uint(sb.x) & keep) | __float_as_uint(W.z), (__float_as_uint(sb.y) & keep) | __float_as_uint(W.w));
+                };
+                for (int k = 0; k < m; k += 8) {
+                    const float4 X0 = *reinterpret_cast<const float4*>(s_x + k), Y0 = *reinterpret_cast<const float4*>(s_y + k),
+                                 Z0 = *reinterpret_cast<const float4*>(s_z + k), W0 = *reinterpret_cast<const float4*>(s_w + k);
+                    const float4 X1 = *reinterpret_cast<const float4*>(s_x + k + 4), Y1 = *reinterpret_cast<const float4*>(s_y + k + 4),
+                                 Z1 = *reinterpret_cast<const float4*>(s_z + k + 4), W1 = *reinterpret_cast<const float4*>(s_w + k + 4);
+                    four(X0, Y0, Z0, W0);
+                    four(X1, Y1, Z1, W1);
                 }
                 if (u1 != before) vlo = lo;
             }
@@ -651,8 +676,13 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         if (lane == 0 && tile < (1u << 18)) { g_nn_tile_t[tile] = (unsigned)(wall_clock64() - tile_t0); g_nn_tile_steps[tile] = tile_steps; g_nn_tile_total[tile] = (unsigned)total; }
 #endif
         const unsigned long long pend = __ballot(valid && !settled);
-        if ((pend >> lane) & 1ull) queue[base + __popcll(pend & ((1ull << lane) - 1ull))] = (unsigned)i;
-        if (lane == 0) qcount[tile] = (unsigned)__popcll(pend);
+        if (pend) {
+            const size_t shard = tile / tiles_per_shard;
+            unsigned at = 0;
+            if (lane == 0) at = atomicAdd(&qcount[shard * 16], (unsigned)__popcll(pend));
+            at = __shfl(at, 0);
+            if ((pend >> lane) & 1ull) queue[shard * tiles_per_shard * 64 + at + __popcll(pend & ((1ull << lane) - 1ull))] = (unsigned)i;
+        }
         if (!valid) continue;
         seed[i] = b.pos;                     // for a queued lane: the candidate its walk starts from
         if (settled && idx_out) idx_out[__float_as_int(s.w)] = b.idx;
@@ -662,37 +692,36 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
 #endif
 }
 
-// The queued source points: eight lanes each, the pyramid walk of nn_search8 from the candidate in seed[]. Tile t's
-// entries start at queue[64 * t], qcount[t] of them; a workgroup takes tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+// The queued source points: eight lanes each, the pyramid walk of nn_search8 from the candidate in seed[]. The work is
+// cut into groups of NN_OCTETS consecutive entries of one part of the queue (see k_icp_tile), numbered part by part,
+// and dealt to the workgroups in turn: the workgroups that are resident together work on one stretch of the cloud
+// (whose cells and pyramid nodes then stay in L2: spreading them over the whole cloud cost a third more time), and
+// over its life every workgroup gets groups from all over the cloud (how long a walk takes depends on where the query is).
+constexpr int WALK_SHARDS = 64;
 __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __restrict__ src, Mat34 T, size_t nt, const unsigned* __restrict__ queue,
-                                                  const unsigned* __restrict__ qcount, size_t ntiles, int* __restrict__ idx_out,
+                                                  const unsigned* __restrict__ qcount, unsigned tiles_per_shard, int* __restrict__ idx_out,
                                                   int* __restrict__ seed) {
     __shared__ unsigned snode[NN_STACK * NN_OCTETS];
     __shared__ double slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
-    __shared__ unsigned s_count[256];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
-    for (size_t r0 = blockIdx.x; r0 < ntiles; r0 += (size_t)gridDim.x * 256) {
-        // the counts of this workgroup's next 256 tiles at once, instead of one dependent load per tile
-        __syncthreads();
-        const size_t mine = r0 + (size_t)threadIdx.x * gridDim.x;
-        s_count[threadIdx.x] = mine < ntiles ? qcount[mine] : 0u;
-        __syncthreads();
-        for (int k = 0; k < 256; k++) {
-            const unsigned count = s_count[k];
-            if (count == 0) continue;
-            const size_t r = r0 + (size_t)k * gridDim.x;
-            for (unsigned e = threadIdx.x >> 3; e < count; e += NN_OCTETS) {
-                const size_t i = queue[r * 64 + e];
-                const float4 s = src[i];
-                double p[3];
-                icp_transform(T, s, p);
-                const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(g, seed, i, nt, p[0], p[1], p[2]));
-                if ((threadIdx.x & 7) != 0) continue;
-                seed[i] = b.pos;
-                if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
-            }
-        }
+    __shared__ unsigned s_count[WALK_SHARDS];
+    if (threadIdx.x < WALK_SHARDS) s_count[threadIdx.x] = qcount[threadIdx.x * 16];
+    __syncthreads();
+    unsigned most = 0;
+    for (int r = 0; r < WALK_SHARDS; r++) most = max(most, s_count[r]);
+    const size_t per_part = (most + NN_OCTETS - 1) / NN_OCTETS, items = per_part * WALK_SHARDS;
+    for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const unsigned shard = (unsigned)(item / per_part), e = (unsigned)(item % per_part) * NN_OCTETS + (threadIdx.x >> 3);
+        if (e >= s_count[shard]) continue;
+        const size_t i = queue[(size_t)shard * tiles_per_shard * 64 + e];
+        const float4 s = src[i];
+        double p[3];
+        icp_transform(T, s, p);
+        const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(g, seed, i, nt, p[0], p[1], p[2]));
+        if ((threadIdx.x & 7) != 0) continue;
+        seed[i] = b.pos;
+        if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
     }
 }
 
@@ -786,10 +815,13 @@ __global__ __launch_bounds__(256) void k_icp_trim_sums(const unsigned* __restric
         partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
+// clear16: nclear words, 16 words apart, set to zero on the way (nullptr: none).
 // Fixed-order final reduction of the block partials (component-major: partials[component * nblocks + block]): one
 // workgroup per component, thread t adds blocks t, t + 256, ... in that order, then a tree over the threads.
-__global__ __launch_bounds__(256) void k_reduce_sums(const double* __restrict__ partials, int nblocks, double* __restrict__ sums) {
+__global__ __launch_bounds__(256) void k_reduce_sums(const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
+                                                     unsigned* __restrict__ clear16 = nullptr, int nclear = 0) {
     __shared__ double sm[256];
+    if (clear16 && blockIdx.x == 0 && (int)threadIdx.x < nclear) clear16[threadIdx.x * 16] = 0u;   // the walk queue's counters, for the next pass
     const double* row = partials + (size_t)blockIdx.x * nblocks;
     double v = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) v += row[b];
@@ -1029,9 +1061,14 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
         ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->tile_counters.p, 0, 8 * 64, ctx->stream));
         ctx->tile_counter_base = 0;
     }
-    ICPX_TRY(icpx_reserve(ctx, ctx->walk_queue, (tiles + tiles * 64) * sizeof(unsigned)));
+    const unsigned tiles_per_shard = (unsigned)((tiles + WALK_SHARDS - 1) / WALK_SHARDS);
+    const size_t queue_words = (size_t)WALK_SHARDS * 16 + (size_t)WALK_SHARDS * tiles_per_shard * 64;
+    if (ctx->walk_queue.cap < queue_words * sizeof(unsigned)) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->walk_queue, queue_words * sizeof(unsigned)));
+        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->walk_queue.p, 0, WALK_SHARDS * 16 * sizeof(unsigned), ctx->stream));   // later passes: k_reduce_sums
+    }
     unsigned* qcount = ctx->walk_queue.as<unsigned>();
-    unsigned* queue = qcount + tiles;
+    unsigned* queue = qcount + WALK_SHARDS * 16;
     // every wave of a group adds once more than it gets tiles, and the group's tiles are added for once each
     const unsigned long long counter_base = ctx->tile_counter_base;
     ctx->tile_counter_base += tiles_per_group + (unsigned long long)(blocks / 8) * TILE_WAVES;
@@ -1040,12 +1077,13 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     const GridView g = view_of(ctx);
     double* part = ctx->partials.as<double>();
     hipLaunchKernelGGL(k_icp_tile, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
-                       ctx->nn_seed.as<int>(), tiles_per_group, ctx->tile_counters.as<unsigned long long>(), counter_base, queue, qcount);
-    hipLaunchKernelGGL(k_icp_walk, dim3((unsigned)std::min<size_t>(tiles, (size_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, g,
-                       ctx->src_pts.as<float4>(), M, ctx->nt, queue, qcount, tiles, idx_dev, ctx->nn_seed.as<int>());
+                       ctx->nn_seed.as<int>(), tiles_per_group, ctx->tile_counters.as<unsigned long long>(), counter_base, queue, qcount, tiles_per_shard);
+    const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, (size_t)ctx->num_cus * 8 / WALK_SHARDS) * WALK_SHARDS);
+    hipLaunchKernelGGL(k_icp_walk, dim3(std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
+                       queue, qcount, tiles_per_shard, idx_dev, ctx->nn_seed.as<int>());
     hipLaunchKernelGGL(k_icp_sums, dim3(sblocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt,
                        ctx->nn_seed.as<int>(), tiles_per_sblock, part);
-    hipLaunchKernelGGL(k_reduce_sums, dim3(ICPX_NSUMS), dim3(256), 0, ctx->stream, part, swaves, sums_dev);
+    hipLaunchKernelGGL(k_reduce_sums, dim3(ICPX_NSUMS), dim3(256), 0, ctx->stream, part, swaves, sums_dev, qcount, WALK_SHARDS);
 #ifdef ICPX_NN_STATS
     {
         unsigned long long h[8];
