@@ -217,6 +217,24 @@ class Context:
                                          lb.ctypes.data_as(C.c_void_p), md.ctypes.data_as(C.c_void_p) if want_mindis else None))
         return (ub, lb, md) if want_mindis else (ub, lb)
 
+    def bnb_eval_async(self, items, out_dev, first=0, count=None):
+        """icpx_bnb_eval_async: this context's share [first, first + count) of the batch into out_dev (CUDA float64, 2 * len(items),
+        [ub..., lb...], zeros for the other items). Only enqueues on the context's stream."""
+        n = len(items)
+        count = n - first if count is None else count
+        self._ck(self._lib.icpx_bnb_eval_async(self._h, C.cast(items, C.c_void_p), n, first, count, C.c_void_p(out_dev.data_ptr())))
+
+    def download(self, dev_tensor, nbytes=None):
+        """icpx_download: waits for the context's stream, returns the tensor's bytes as a numpy array of its dtype."""
+        out = np.empty(tuple(dev_tensor.shape), {8: np.float64, 4: np.int32}[dev_tensor.element_size()])
+        self._ck(self._lib.icpx_download(self._h, C.c_void_p(dev_tensor.data_ptr()), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def edt_grid_ptr(self):
+        p = C.c_void_p()
+        self._ck(self._lib.icpx_edt_grid_ptr(self._h, C.byref(p)))
+        return p.value
+
     def bnb_eval_noalloc(self, items_dev, nitems, out_dev):
         """icpx_bnb_eval_noalloc: items_dev a CUDA uint8 tensor holding `nitems` packed icpx_bnb_item records, out_dev a
         CUDA float64 tensor of 2 * nitems ([ub..., lb...]). Only enqueues on the context's stream: sync() before reading."""

@@ -499,6 +499,21 @@ void GoIcp::eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub
     size_t lo = 0, hi = n;
     if (comm.world > 1) { lo = n * comm.rank / comm.world; hi = n * (comm.rank + 1) / comm.world; }
     std::vector<double> both(2 * n, 0.0);
+    if (comm.world > 1 && comm.allreduce_sum_dev && comm.dev_buffer && comm.dev_capacity >= 16 && !parity_sums) {
+        // Device side: every rank evaluates its share of the batch into the same layout (zeros elsewhere), the sum over
+        // the ranks runs on the GPUs on the context's stream, and one copy brings all bounds to the host.
+        const size_t cap = comm.dev_capacity / 2;
+        for (size_t c0 = 0; c0 < n; c0 += cap) {
+            const size_t m = std::min(cap, n - c0);
+            const size_t a = m * comm.rank / comm.world, b = m * (comm.rank + 1) / comm.world;
+            dev->check(icpx_bnb_eval_async(dev->ctx(), items.data() + c0, m, a, b - a, comm.dev_buffer));
+            comm.allreduce_sum_dev(comm.dev_buffer, (int)(2 * m), comm.user);
+            std::vector<double> part(2 * m);
+            dev->check(icpx_download(dev->ctx(), comm.dev_buffer, part.data(), 2 * m * sizeof(double)));
+            for (size_t k = 0; k < m; k++) { ub[c0 + k] = (float)part[k]; lb[c0 + k] = (float)part[m + k]; }
+        }
+        return;
+    }
     if (hi > lo) {
         const size_t m = hi - lo;
         if (parity_sums) {
@@ -570,7 +585,7 @@ static TransNode child_of(const TransNode& parent, int j) {
     return node;
 }
 
-void GoIcp::run_searches(std::vector<Search>& ss) {
+void GoIcp::run_searches(const std::vector<Search*>& ss) {
     std::vector<icpx_bnb_item> items;
     std::vector<float> ub, lb;
     const int width = std::max(1, frontier_width);
@@ -590,7 +605,8 @@ void GoIcp::run_searches(std::vector<Search>& ss) {
     };
     for (;;) {
         items.clear();
-        for (Search& s : ss) {
+        for (Search* sp : ss) {
+            Search& s = *sp;
             s.pending.clear();
             if (s.done) continue;
             // parents whose children were evaluated ahead of time need no launch
@@ -634,7 +650,8 @@ void GoIcp::run_searches(std::vector<Search>& ss) {
         if (items.empty()) break;
         eval_items(items, ub, lb);
         size_t pos = 0;
-        for (Search& s : ss) {
+        for (Search* sp : ss) {
+            Search& s = *sp;
             const size_t popped = std::min<size_t>(s.pending.size(), (size_t)width);
             for (size_t k = 0; k < s.pending.size(); k++, pos += 8) {
                 if (k < popped) { if (!s.done) take(s, s.pending[k], &ub[pos], &lb[pos]); }   // an earlier parent of this batch may have ended the search
@@ -649,15 +666,14 @@ void GoIcp::run_searches(std::vector<Search>& ss) {
 }
 
 float GoIcp::innerBnB(float* maxDistL, TransNode* transOut) {
-    std::vector<Search> ss(1);
-    Search& s = ss[0];
+    Search s;
     std::memcpy(s.R, R_, sizeof R_);
     s.level = cur_level_of(maxDistL);
     s.que.push(InitTrans);
     s.optErrorT = optError;
     const int keep = frontier_width;
     frontier_width = 1;                 // the reference pops one parent at a time
-    run_searches(ss);
+    run_searches(std::vector<Search*>{&s});
     frontier_width = keep;
     if (transOut && s.have_best) *transOut = s.best;
     return s.optErrorT;
@@ -683,7 +699,6 @@ static bool rotation_of(float v1, float v2, float v3, float R[9]) {
 }
 
 float GoIcp::OuterBnB() {
-    std::priority_queue<RotNode> que;
     rot_pops = inner_evals = launches = 0;
 
     // initial error: identity pose, sequential float sum (src/GoIcp.cpp:159-172)
@@ -701,17 +716,17 @@ float GoIcp::OuterBnB() {
     final_lb = 0;
     if (!run_bnb) return 0.0f;   // the committed code returns here (src/GoIcp.cpp:189)
 
-    que.push(InitRot);
-    for (;;) {
-        if (que.empty()) break;
-        const RotNode parent = que.top(); que.pop();
-        final_lb = parent.lb;
-        if (optError - parent.lb < sseThresh) break;
-        if (max_rot_pops > 0 && rot_pops >= max_rot_pops) break;
-        rot_pops++;
-
-        struct Child { RotNode node; float R[9]; };
-        std::vector<Child> kids;
+    // Work of one rotation parent: its child cubes inside the pi-ball with their rotations, and (batched mode) the two
+    // inner searches of every child — upper-bound form, lower-bound form — started from the optError of that moment.
+    struct Child { RotNode node; float R[9]; };
+    struct Work { RotNode parent; std::vector<Child> kids; std::vector<Search> ss; float optAtStart; };
+    auto same_cube = [](const RotNode& x, const RotNode& y) {
+        return std::memcmp(&x.a, &y.a, sizeof(float)) == 0 && std::memcmp(&x.b, &y.b, sizeof(float)) == 0 &&
+               std::memcmp(&x.c, &y.c, sizeof(float)) == 0 && std::memcmp(&x.w, &y.w, sizeof(float)) == 0 && x.l == y.l;
+    };
+    auto prepare = [&](const RotNode& parent, Work& w) {
+        w.parent = parent;
+        w.optAtStart = optError;
         RotNode nodeRot;
         nodeRot.l = parent.l + 1;
         nodeRot.w = parent.w / 2;
@@ -725,23 +740,86 @@ float GoIcp::OuterBnB() {
             Child c;
             c.node = nodeRot;
             rotation_of(v1, v2, v3, c.R);
-            kids.push_back(c);
+            w.kids.push_back(c);
         }
+        if (!batched) return;
+        w.ss.resize(2 * w.kids.size());
+        for (size_t k = 0; k < w.kids.size(); k++)
+            for (int form = 0; form < 2; form++) {
+                Search& s = w.ss[2 * k + form];
+                std::memcpy(s.R, w.kids[k].R, sizeof s.R);
+                s.level = form == 0 ? -1 : std::min(w.kids[k].node.l, MAXROTLEVEL - 1);
+                s.que.push(InitTrans);
+                s.optErrorT = optError;
+            }
+    };
+    struct RotQueue : std::priority_queue<RotNode> {
+        const std::vector<RotNode>& heap() const { return c; }
+    };
+    RotQueue rq;
+    std::vector<std::unique_ptr<Work>> ahead_of_time;   // searched already: valid while optError stays what it was
+    spec_hits = spec_misses = 0;
 
-        std::vector<Search> ss;
+    rq.push(InitRot);
+    for (;;) {
+        if (rq.empty()) break;
+        const RotNode parent = rq.top(); rq.pop();
+        final_lb = parent.lb;
+        if (optError - parent.lb < sseThresh) break;
+        if (max_rot_pops > 0 && rot_pops >= max_rot_pops) break;
+        rot_pops++;
+
+        std::unique_ptr<Work> cur;
         if (batched) {
-            // the 2 x |kids| inner searches advance together; each starts from the current optError
-            ss.resize(2 * kids.size());
-            for (size_t k = 0; k < kids.size(); k++)
-                for (int form = 0; form < 2; form++) {
-                    Search& s = ss[2 * k + form];
-                    std::memcpy(s.R, kids[k].R, sizeof s.R);
-                    s.level = form == 0 ? -1 : std::min(kids[k].node.l, MAXROTLEVEL - 1);
-                    s.que.push(InitTrans);
-                    s.optErrorT = optError;
+            // what was searched ahead of time stands only if optError is still the value those searches started from
+            for (size_t k = 0; k < ahead_of_time.size();) {
+                if (std::memcmp(&ahead_of_time[k]->optAtStart, &optError, sizeof(float)) != 0) {
+                    spec_misses++;
+                    ahead_of_time.erase(ahead_of_time.begin() + k);
+                } else k++;
+            }
+            for (size_t k = 0; k < ahead_of_time.size(); k++)
+                if (same_cube(ahead_of_time[k]->parent, parent)) {
+                    cur = std::move(ahead_of_time[k]);
+                    ahead_of_time.erase(ahead_of_time.begin() + k);
+                    spec_hits++;
+                    break;
                 }
-            run_searches(ss);
+            std::vector<Search*> run;
+            if (!cur) {
+                cur.reset(new Work);
+                prepare(parent, *cur);
+                for (Search& s : cur->ss) run.push_back(&s);
+            }
+            // the cubes most likely to be popped next: the best of the queue as it stands
+            if (speculate > 0) {
+                const std::vector<RotNode>& h = rq.heap();
+                std::vector<size_t> cand;
+                if (!h.empty()) cand.push_back(0);
+                for (int k = 0; k < speculate && !cand.empty(); k++) {
+                    size_t bi = 0;
+                    for (size_t c = 1; c < cand.size(); c++) if (h[cand[c]].lb < h[cand[bi]].lb) bi = c;
+                    const size_t i = cand[bi];
+                    cand[bi] = cand.back(); cand.pop_back();
+                    if (2 * i + 1 < h.size()) cand.push_back(2 * i + 1);
+                    if (2 * i + 2 < h.size()) cand.push_back(2 * i + 2);
+                    if (optError - h[i].lb < sseThresh) continue;          // the search would stop at this cube
+                    bool known = false;
+                    for (const auto& w : ahead_of_time) known = known || same_cube(w->parent, h[i]);
+                    if (known) continue;
+                    if (ahead_of_time.size() >= (size_t)(4 * speculate)) { ahead_of_time.erase(ahead_of_time.begin()); spec_misses++; }
+                    ahead_of_time.emplace_back(new Work);
+                    prepare(h[i], *ahead_of_time.back());
+                    for (Search& s : ahead_of_time.back()->ss) run.push_back(&s);
+                }
+            }
+            if (!run.empty()) run_searches(run);
+        } else {
+            cur.reset(new Work);
+            prepare(parent, *cur);
         }
+        const std::vector<Child>& kids = cur->kids;
+        std::vector<Search>& ss = cur->ss;
 
         bool finished = false;
         for (size_t k = 0; k < kids.size() && !finished; k++) {
@@ -765,12 +843,12 @@ float GoIcp::OuterBnB() {
                 error = runICP(tmpMat);
                 if (error < optError) { optError = error; optMat = tmpMat; }
                 // drop queued rotation cubes that can no longer improve (src/GoIcp.cpp:317-328)
-                std::priority_queue<RotNode> keep;
-                while (!que.empty()) {
-                    const RotNode n = que.top(); que.pop();
+                RotQueue keep;
+                while (!rq.empty()) {
+                    const RotNode n = rq.top(); rq.pop();
                     if (n.lb < optError) keep.push(n); else break;
                 }
-                que = keep;
+                rq = keep;
             }
             const int lvl = std::min(node.l, MAXROTLEVEL - 1);
             float lb;
@@ -780,10 +858,11 @@ float GoIcp::OuterBnB() {
             if (lb >= optError) continue;
             node.lb = lb; node.ub = ub;
             if (optError - parent.lb < sseThresh) { finished = true; break; }
-            que.push(node);
+            rq.push(node);
         }
         if (finished) break;
     }
+    spec_misses += (long long)ahead_of_time.size();
     return optError;
 }
 
@@ -824,7 +903,9 @@ PointCloudTPtr make_cloud(const float* xyz, size_t n) {
 }
 struct HCollective {
     void (*allreduce_host)(double*, int) = nullptr;
+    void (*allreduce_dev)(double*, int) = nullptr;
     static void tramp(double* p, int n, void* user) { ((HCollective*)user)->allreduce_host(p, n); }
+    static void tramp_dev(double* p, int n, void* user) { ((HCollective*)user)->allreduce_dev(p, n); }
 };
 struct HIcp { DevicePtr dev; PointCloudTPtr src, tgt; std::unique_ptr<SingleThreadIcp> icp; HCollective hc; };
 struct HGo { DevicePtr dev; PointCloudTPtr model, data; std::unique_ptr<GoIcp> go; HCollective hc; };
@@ -1006,11 +1087,26 @@ void* icpxh_goicp_new(int device, const float* model, size_t nm, const float* da
     return h;
 }
 void icpxh_goicp_free(void* p) { delete (HGo*)p; }
-int icpxh_goicp_options(void* p, int run_bnb, int batched, int parity_sums, int frontier_width, long long max_rot_pops, int lookahead) {
+int icpxh_goicp_options(void* p, int run_bnb, int batched, int parity_sums, int frontier_width, long long max_rot_pops, int lookahead,
+                        int speculate) {
     HGo* h = (HGo*)p;
     h->go->run_bnb = run_bnb != 0; h->go->batched = batched != 0; h->go->parity_sums = parity_sums != 0;
     h->go->frontier_width = frontier_width; h->go->max_rot_pops = max_rot_pops; h->go->lookahead = lookahead;
+    h->go->speculate = speculate;
     return 0;
+}
+// Device-side collective: allreduce_dev sums n doubles at a device address inside [dev_buffer, dev_buffer + capacity) over
+// the ranks, in place, on the stream given here (which the context then uses for everything).
+int icpxh_goicp_set_collective_dev(void* p, int rank, int world, void (*allreduce_dev)(double*, int), double* dev_buffer,
+                                   size_t capacity, void* hip_stream) {
+    return guard([&] {
+        HGo* h = (HGo*)p;
+        h->hc.allreduce_dev = allreduce_dev;
+        h->go->comm.rank = rank; h->go->comm.world = world; h->go->comm.user = &h->hc;
+        h->go->comm.allreduce_sum_dev = &HCollective::tramp_dev;
+        h->go->comm.dev_buffer = dev_buffer; h->go->comm.dev_capacity = capacity;
+        h->dev->check(icpx_set_stream(h->dev->ctx(), hip_stream));
+    });
 }
 int icpxh_goicp_set_collective(void* p, int rank, int world, void (*allreduce)(double*, int)) {
     HGo* h = (HGo*)p;
@@ -1019,7 +1115,7 @@ int icpxh_goicp_set_collective(void* p, int rank, int world, void (*allreduce)(d
     h->go->comm.allreduce_sum_host = &HCollective::tramp;
     return 0;
 }
-// stats8: optError, initError, icpError, rot_pops, inner_evals, final_lb, launches, sseThresh
+// stats: optError, initError, icpError, rot_pops, inner_evals, final_lb, launches, sseThresh, spec_hits, spec_misses
 int icpxh_goicp_registration(void* p, double* optMat16, double* stats8, double* resN3) {
     return guard([&] {
         HGo* h = (HGo*)p;
@@ -1028,6 +1124,7 @@ int icpxh_goicp_registration(void* p, double* optMat16, double* stats8, double* 
         stats8[0] = h->go->optError; stats8[1] = h->go->initError; stats8[2] = h->go->icpError;
         stats8[3] = (double)h->go->rot_pops; stats8[4] = (double)h->go->inner_evals; stats8[5] = h->go->final_lb;
         stats8[6] = (double)h->go->launches; stats8[7] = h->go->sseThresh;
+        stats8[8] = (double)h->go->spec_hits; stats8[9] = (double)h->go->spec_misses;
         if (resN3) std::memcpy(resN3, r.resN3.data.data(), r.resN3.data.size() * sizeof(double));
     });
 }

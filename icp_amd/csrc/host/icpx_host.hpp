@@ -100,8 +100,12 @@ using DevicePtr = std::shared_ptr<Device>;
 struct Collective {
     int rank = 0, world = 1;
     void* user = nullptr;
-    // in-place sum over ranks of n doubles that live in DEVICE memory of this rank's GPU
+    // in-place sum over ranks of n doubles that live in DEVICE memory of this rank's GPU, enqueued on the stream the
+    // rank's icpx context uses (RCCL through the caller's communicator; icpx_set_stream makes the two streams one)
     void (*allreduce_sum_dev)(double* dev, int n, void* user) = nullptr;
+    // device memory of this rank's GPU that the classes may use for what they hand to allreduce_sum_dev
+    double* dev_buffer = nullptr;
+    size_t dev_capacity = 0;      // in doubles
     // in-place sum over ranks of n doubles in HOST memory
     void (*allreduce_sum_host)(double* host, int n, void* user) = nullptr;
 };
@@ -278,6 +282,13 @@ public:
     // search pops those cubes. A bound depends on the cube alone, so the search takes exactly the decisions of the
     // reference's order, in fewer and larger launches; bounds of cubes that are never popped are wasted work.
     int lookahead = 4;            // bunny pair: 93 490 launches with 0, 29 634 with 4 (about 40 % less time), 24 285 with 16 (more time again)
+    // Rotation cubes whose inner searches run ahead of time, in the same launches as those of the cube just popped
+    // (batched mode): the `speculate` cubes that follow it in the rotation queue. Their searches start from the current
+    // optError, so what they find is what the search would find later, as long as optError has not changed by then and
+    // the cube is indeed popped next; otherwise it is thrown away. Decisions and result are those of speculate = 0; the
+    // launches carry (1 + speculate) times as many cubes, which is what several GPUs sharing every launch need.
+    int speculate = 0;
+    long long spec_hits = 0, spec_misses = 0;
     long long max_rot_pops = 0;   // 0 = unlimited
     Collective comm;              // world > 1: every bound batch is split over the ranks
     // statistics
@@ -291,7 +302,7 @@ private:
     float R_[9];                                   // rotation of the current cube (innerBnB operates on it)
     int cur_level_of(const float* maxDistL) const;
     void eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub, std::vector<float>& lb);
-    void run_searches(std::vector<Search>& ss);
+    void run_searches(const std::vector<Search*>& ss);
 };
 
 }  // namespace icp

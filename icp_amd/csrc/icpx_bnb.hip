@@ -80,13 +80,17 @@ __global__ __launch_bounds__(256) void k_bnb_eval(EdtView e, const float4* __res
     }
 }
 
-__global__ void k_bnb_reduce(const double* __restrict__ partials, int nitems, int nsplit, double* __restrict__ out) {
+// out: [ub_0 .. ub_{total-1}, lb_0 .. lb_{total-1}]. The partials belong to items first .. first + count - 1 of the batch; the
+// other entries (other ranks' shares of a batch that is summed over the ranks afterwards) are set to zero.
+__global__ void k_bnb_reduce(const double* __restrict__ partials, int total, int first, int count, int nsplit, double* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nitems) return;
+    if (i >= total) return;
     double ub = 0.0, lb = 0.0;
-    for (int s = 0; s < nsplit; s++) { ub += partials[((size_t)i * nsplit + s) * 2]; lb += partials[((size_t)i * nsplit + s) * 2 + 1]; }
+    const int k = i - first;
+    if (k >= 0 && k < count)
+        for (int s = 0; s < nsplit; s++) { ub += partials[((size_t)k * nsplit + s) * 2]; lb += partials[((size_t)k * nsplit + s) * 2 + 1]; }
     out[i] = ub;
-    out[nitems + i] = lb;
+    out[total + i] = lb;
 }
 
 struct Mat34 { double m[12]; };
@@ -206,30 +210,33 @@ static int bnb_pin_reserve(icpx_ctx* ctx, size_t bytes) {
     return ICPX_OK;
 }
 
-static int bnb_enqueue(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev, float* mindis_dev) {
+// Evaluates items[0 .. nitems) — entries first .. first + nitems - 1 of a batch of `total` — into out_dev (2 * total doubles).
+static int bnb_enqueue(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev, float* mindis_dev, size_t total, size_t first) {
     if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_eval: no EDT has been built");
     if (ctx->nd == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_eval: no data cloud (call icpx_goicp_set_data first)");
-    if (!items) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval: items is NULL");
-    if (nitems > 65535u * 16u) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_bnb_eval: more than 1048560 items in one batch");
+    if (!items && nitems) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval: items is NULL");
+    if (total > 65535u * 16u) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_bnb_eval: more than 1048560 items in one batch");
     for (size_t i = 0; i < nitems; i++)
         if (items[i].level >= ICPX_MAXROTLEVEL) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval: item %zu has level %d >= %d", i, items[i].level, ICPX_MAXROTLEVEL);
     const size_t n = ctx->nd;
     const int nsplit = bnb_slices(n);
-    ICPX_TRY(icpx_reserve(ctx, ctx->bnb_items, nitems * sizeof(icpx_bnb_item)));
-    ICPX_TRY(icpx_reserve(ctx, ctx->bnb_partials, nitems * nsplit * 2 * sizeof(double)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->bnb_items, std::max<size_t>(nitems, 1) * sizeof(icpx_bnb_item)));
+    ICPX_TRY(icpx_reserve(ctx, ctx->bnb_partials, std::max<size_t>(nitems, 1) * nsplit * 2 * sizeof(double)));
     // The item list goes through the pinned buffer (front part; the results come back into the part behind
     // it), so the caller may reuse `items` as soon as this function returns. A previous batch that is still
     // in flight on the stream would read the same staging area: batches are serialised here.
     const size_t items_bytes = nitems * sizeof(icpx_bnb_item);
-    ICPX_TRY(bnb_pin_reserve(ctx, items_bytes + 2 * nitems * sizeof(double)));
+    ICPX_TRY(bnb_pin_reserve(ctx, items_bytes + 2 * total * sizeof(double)));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::memcpy(ctx->bnb_pin, items, items_bytes);
-    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->bnb_items.p, ctx->bnb_pin, items_bytes, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nitems, (unsigned)nsplit), dim3(256), 0, ctx->stream, edt_view(ctx),
-                       ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), ctx->bnb_items.as<icpx_bnb_item>(), nsplit,
-                       ctx->bnb_partials.as<double>(), mindis_dev);
-    hipLaunchKernelGGL(k_bnb_reduce, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bnb_partials.as<double>(),
-                       (int)nitems, nsplit, out_dev);
+    if (nitems) {
+        std::memcpy(ctx->bnb_pin, items, items_bytes);
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->bnb_items.p, ctx->bnb_pin, items_bytes, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nitems, (unsigned)nsplit), dim3(256), 0, ctx->stream, edt_view(ctx),
+                           ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), ctx->bnb_items.as<icpx_bnb_item>(), nsplit,
+                           ctx->bnb_partials.as<double>(), mindis_dev);
+    }
+    hipLaunchKernelGGL(k_bnb_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bnb_partials.as<double>(),
+                       (int)total, (int)first, (int)nitems, nsplit, out_dev);
     return icpx_launch_check(ctx, "k_bnb_eval");
 }
 
@@ -247,7 +254,7 @@ extern "C" int icpx_bnb_eval(icpx_ctx* ctx, const icpx_bnb_item* items, size_t n
     // command fewer per batch. The buffer is sized here so that the address is known before the launch.
     ICPX_TRY(bnb_pin_reserve(ctx, nitems * sizeof(icpx_bnb_item) + 2 * nitems * sizeof(double)));
     double* res = reinterpret_cast<double*>(static_cast<char*>(ctx->bnb_pin) + nitems * sizeof(icpx_bnb_item));
-    ICPX_TRY(bnb_enqueue(ctx, items, nitems, res, md));
+    ICPX_TRY(bnb_enqueue(ctx, items, nitems, res, md, nitems, 0));
     if (mindis_opt)
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(mindis_opt, md, nitems * ctx->nd * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -256,12 +263,27 @@ extern "C" int icpx_bnb_eval(icpx_ctx* ctx, const icpx_bnb_item* items, size_t n
     return ICPX_OK;
 }
 
-extern "C" int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev) {
+extern "C" int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, size_t first, size_t count, double* out_dev) {
     if (!ctx) return ICPX_EINVAL;
     if (nitems == 0) return ICPX_OK;
     if (!out_dev) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval_async: out_dev is NULL");
+    if (first > nitems || count > nitems - first) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval_async: the share [first, first + count) lies outside the batch");
+    if (!items) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval_async: items is NULL");
     ICPX_TRY(icpx_bind(ctx));
-    return bnb_enqueue(ctx, items, nitems, out_dev, nullptr);
+    return bnb_enqueue(ctx, items + first, count, out_dev, nullptr, nitems, first);
+}
+
+extern "C" int icpx_download(icpx_ctx* ctx, const void* dev, void* host, size_t bytes) {
+    if (!ctx) return ICPX_EINVAL;
+    if (bytes == 0) return ICPX_OK;
+    if (!dev || !host) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_download: NULL pointer");
+    ICPX_TRY(icpx_bind(ctx));
+    // through the context's pinned staging area: one DMA, where a pageable destination is staged by the runtime in pieces
+    ICPX_TRY(bnb_pin_reserve(ctx, bytes));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->bnb_pin, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(host, ctx->bnb_pin, bytes);
+    return ICPX_OK;
 }
 
 extern "C" int icpx_bnb_eval_noalloc(icpx_ctx* ctx, const icpx_bnb_item* items_dev, size_t nitems, double* out_dev) {
@@ -281,7 +303,7 @@ extern "C" int icpx_bnb_eval_noalloc(icpx_ctx* ctx, const icpx_bnb_item* items_d
     double* part = ctx->bnb_scratch;
     hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nitems, (unsigned)nsplit), dim3(256), 0, ctx->stream, edt_view(ctx),
                        ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), items_dev, nsplit, part, (float*)nullptr);
-    hipLaunchKernelGGL(k_bnb_reduce, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, ctx->stream, part, (int)nitems, nsplit, out_dev);
+    hipLaunchKernelGGL(k_bnb_reduce, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, ctx->stream, part, (int)nitems, 0, (int)nitems, nsplit, out_dev);
     return icpx_launch_check(ctx, "k_bnb_eval (noalloc)");
 }
 

@@ -40,7 +40,8 @@ def _lib():
         lib.icpxh_icp3d_free.argtypes = [C.c_void_p]; lib.icpxh_icp3d_free.restype = None
         lib.icpxh_icp3d_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_int,
                                         C.c_double, C.c_void_p, C.c_void_p]
-        lib.icpxh_goicp_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int]
+        lib.icpxh_goicp_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int]
+        lib.icpxh_goicp_set_collective_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.icpxh_goicp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
         lib.icpxh_goicp_registration.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.icpxh_goicp_inner.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
@@ -236,24 +237,40 @@ class ICP3D:
 
 
 class GoIcp:
-    def __init__(self, model, data, mse=1e-3, dt_div=300, device=0, allreduce=None, rank=0, world=1):
+    """world > 1: every bound batch is shared by the ranks. Either `allreduce` (in-place sum of a host float64 array over
+    the ranks) or, for the device-side path, `allreduce_dev` (in-place sum of a float64 CUDA tensor over the ranks on
+    torch's current stream, e.g. torch.distributed.all_reduce over RCCL) together with `dev_buffer`, a float64 CUDA
+    tensor the bounds travel in (2 doubles per cube of a batch; larger batches go in pieces)."""
+    def __init__(self, model, data, mse=1e-3, dt_div=300, device=0, allreduce=None, rank=0, world=1, allreduce_dev=None, dev_buffer=None):
         self._m, self._d = _f32(model), _f32(data)
         self._h = _new(_lib().icpxh_goicp_new(device, _vp(self._m), self._m.shape[0], _vp(self._d), self._d.shape[0], mse, dt_div))
         self._cb = None
-        if world > 1:
+        if world > 1 and allreduce_dev is not None:
+            import torch
+            self._buf = dev_buffer
+            base, n8 = dev_buffer.data_ptr(), dev_buffer.numel()
+
+            def cb(ptr, n):
+                off = (C.cast(ptr, C.c_void_p).value - base) // 8
+                allreduce_dev(self._buf[off:off + n])
+            self._cb = _ALLREDUCE(cb)
+            _ck(_lib().icpxh_goicp_set_collective_dev(self._h, rank, world, self._cb, C.c_void_p(base), n8,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        elif world > 1:
             self._cb = make_allreduce(allreduce)
             _ck(_lib().icpxh_goicp_set_collective(self._h, rank, world, self._cb))
 
-    def options(self, run_bnb=True, batched=True, parity_sums=False, frontier_width=1, max_rot_pops=0, lookahead=4):
-        _ck(_lib().icpxh_goicp_options(self._h, int(run_bnb), int(batched), int(parity_sums), frontier_width, max_rot_pops, lookahead))
+    def options(self, run_bnb=True, batched=True, parity_sums=False, frontier_width=1, max_rot_pops=0, lookahead=4, speculate=0):
+        _ck(_lib().icpxh_goicp_options(self._h, int(run_bnb), int(batched), int(parity_sums), frontier_width, max_rot_pops, lookahead, speculate))
         return self
 
     def registration(self, want_points=False):
-        M = np.empty(16); st = np.zeros(8)
+        M = np.empty(16); st = np.zeros(10)
         res = np.empty((self._d.shape[0], 3)) if want_points else None
         _ck(_lib().icpxh_goicp_registration(self._h, _vp(M), _vp(st), _vp(res)))
         return dict(optMat=M.reshape(4, 4), optError=np.float32(st[0]), initError=np.float32(st[1]), icpError=np.float32(st[2]),
-                    rot_pops=int(st[3]), inner_evals=int(st[4]), lb=st[5], launches=int(st[6]), sseThresh=st[7], resN3=res)
+                    rot_pops=int(st[3]), inner_evals=int(st[4]), lb=st[5], launches=int(st[6]), sseThresh=st[7], spec_hits=int(st[8]),
+                    spec_misses=int(st[9]), resN3=res)
 
     def innerBnB(self, R, level, optError):
         R = _f32(R).reshape(9); out = C.c_float(); tr = np.empty(4, np.float32)

@@ -196,10 +196,18 @@ typedef struct icpx_bnb_item {
  * which the reference's sequential float sums (:416-431) can be reproduced bit for bit. */
 int icpx_bnb_eval(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* ub, double* lb, float* mindis_opt);
 
-/* Enqueue-only variant for multi-GPU use: out_dev is DEVICE memory, 2 * nitems doubles laid out
- * [ub_0 .. ub_{n-1}, lb_0 .. lb_{n-1}]. items is host memory and is copied before the call returns (through
- * one pinned staging area per context: the call first waits for earlier work on the context's stream). */
-int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev);
+/* Enqueue-only variant for several GPUs that share one batch: this context evaluates items first .. first + count - 1
+ * of the nitems items and writes all of out_dev — DEVICE memory, 2 * nitems doubles laid out
+ * [ub_0 .. ub_{n-1}, lb_0 .. lb_{n-1}] — with zeros in the entries of the other items, so that a sum over the ranks
+ * (an all-reduce on the same stream) leaves every bound on every rank. first = 0, count = nitems evaluates the whole
+ * batch. items is host memory (the whole batch) and is copied before the call returns (through one pinned staging area
+ * per context: the call first waits for earlier work on the context's stream). The loop being shared is the child loop of
+ * GoIcp::innerBnB (src/GoIcp.cpp:381-431). */
+int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, size_t first, size_t count, double* out_dev);
+
+/* Waits for the context's stream and copies `bytes` of device memory to host memory (results of the _async entry
+ * points that the caller left in its own device buffers). No counterpart in the reference. */
+int icpx_download(icpx_ctx* ctx, const void* dev, void* host, size_t bytes);
 
 /* No counterpart in the reference. For callers that cannot allocate device memory while they run (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc): the same bounds as icpx_bnb_eval_async
