@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
             SingleThreadIcp icp(src, tgt, ite, dev);
             Matrix4d guess = Matrix4d::Identity();
             ICP_res r = icp.registration(guess, src);
-            std::printf("ICP, %d iterations, NN mse %.6e -> %.6e\ntransMat:\n", ite, icp.mse_trace.front(), icp.mse_trace.back());
+            std::printf("ICP, %d iterations, each transform mse %.6e -> %.6e\ntransMat:\n", ite, icp.mse_trace.front(), icp.mse_trace.back());
             print_mat(r.transMat);
         } else if (!std::strcmp(mode, "goicp")) {
             const double s = normalize_goicp(*tgt, *src);

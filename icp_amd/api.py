@@ -17,13 +17,18 @@ def _is_torch(a):
     return hasattr(a, "data_ptr") and hasattr(a, "is_cuda")
 
 
-def _ptr(a, dtype, shape_last=None):
-    """(pointer, where, count) of a C-contiguous numpy array or CUDA tensor of the given dtype."""
+def _ptr(a, dtype, ctx=None):
+    """(pointer, where) of a C-contiguous numpy array or CUDA tensor of the given dtype. A CUDA tensor may still be
+    being written by work on torch's current stream: unless the context launches on that very stream (set_stream), the
+    stream is drained first, so that the library's own stream never reads a tensor before torch has produced it."""
     if _is_torch(a):
         import torch
         want = {np.float32: torch.float32, np.float64: torch.float64, np.int32: torch.int32}[dtype]
         if a.dtype != want or not a.is_contiguous() or not a.is_cuda:
             raise TypeError(f"expected a contiguous CUDA tensor of {want}")
+        cur = torch.cuda.current_stream(a.device)
+        if ctx is None or ctx._stream != cur.cuda_stream:
+            cur.synchronize()
         return C.c_void_p(a.data_ptr()), DEVICE
     if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags.c_contiguous:
         raise TypeError(f"expected a C-contiguous numpy array of {np.dtype(dtype)}")
@@ -38,6 +43,7 @@ class Context:
         if rc != 0:
             raise IcpxError(rc, self._lib.icpx_last_error(None).decode())
         self._h = h
+        self._stream = -1              # the context's own stream (not one of torch's)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -57,21 +63,23 @@ class Context:
     def set_stream(self, stream_ptr):
         """stream_ptr: a hipStream_t as an integer (torch.cuda.current_stream().cuda_stream); 0 is the default stream."""
         self._ck(self._lib.icpx_set_stream(self._h, C.c_void_p(stream_ptr)))
+        self._stream = stream_ptr
 
     def reset_stream(self):
         self._ck(self._lib.icpx_reset_stream(self._h))
+        self._stream = -1
 
     def sync(self):
         self._ck(self._lib.icpx_sync(self._h))
 
     # ---- target / NN ----
     def set_target(self, xyz):
-        p, where = _ptr(xyz, np.float32)
+        p, where = _ptr(xyz, np.float32, self)
         n, stride = xyz.shape[0], 4 * xyz.shape[1]
         self._ck(self._lib.icpx_set_target(self._h, p, n, stride, where))
 
     def nn(self, q, want_d2=True):
-        p, where = _ptr(q, np.float64)
+        p, where = _ptr(q, np.float64, self)
         n = q.shape[0]
         if where == DEVICE:
             import torch
@@ -94,7 +102,7 @@ class Context:
         return idx, d2
 
     def nn_distance(self, q):
-        p, where = _ptr(q, np.float32)
+        p, where = _ptr(q, np.float32, self)
         n = q.shape[0]
         if where == DEVICE:
             import torch
@@ -106,7 +114,7 @@ class Context:
 
     # ---- ICP step ----
     def set_source(self, xyz):
-        p, where = _ptr(xyz, np.float32)
+        p, where = _ptr(xyz, np.float32, self)
         self._ck(self._lib.icpx_set_source(self._h, p, xyz.shape[0], 4 * xyz.shape[1], where))
         self._ns = xyz.shape[0]
 
@@ -127,7 +135,7 @@ class Context:
 
     def icp_step_async(self, T, sums_dev):
         T = np.ascontiguousarray(T, np.float64).reshape(16)
-        p, where = _ptr(sums_dev, np.float64)
+        p, where = _ptr(sums_dev, np.float64, self)
         assert where == DEVICE
         self._ck(self._lib.icpx_icp_step_async(self._h, T.ctypes.data_as(C.c_void_p), p))
 
@@ -171,12 +179,12 @@ class Context:
         div = self.edt_info()["div"]
         if out is None:
             out = np.empty((div, div, div), np.int32)
-        p, where = _ptr(out, np.int32)
+        p, where = _ptr(out, np.int32, self)
         self._ck(self._lib.icpx_edt_read(self._h, p, where))
         return out
 
     def edt_lookup(self, q):
-        p, where = _ptr(q, np.float32)
+        p, where = _ptr(q, np.float32, self)
         n = q.shape[0]
         if where == DEVICE:
             import torch
@@ -188,7 +196,7 @@ class Context:
 
     # ---- Go-ICP ----
     def goicp_set_data(self, xyz):
-        p, where = _ptr(xyz, np.float32)
+        p, where = _ptr(xyz, np.float32, self)
         self._ck(self._lib.icpx_goicp_set_data(self._h, p, xyz.shape[0], 4 * xyz.shape[1], where))
         self._nd = xyz.shape[0]
 

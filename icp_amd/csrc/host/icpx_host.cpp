@@ -132,17 +132,23 @@ void Device::check(int rc) const {
 
 static void ensure_target_on(const DevicePtr& dev, const PointCloudTPtr& cloud) {
     if (!cloud || cloud->points.empty()) throw IcpxFailure(ICPX_EINVAL, "empty target cloud");
-    if (dev->target_tag == cloud.get()) return;
+    // The same cloud object (still alive, so its address cannot have been given to another one), same size, same storage:
+    // already on the GPU. Points changed in place are not noticed: call Device::forget_target() after that.
+    if (!dev->target_ref.expired() && dev->target_ref.lock() == cloud && dev->target_n == cloud->points.size() &&
+        dev->target_first == cloud->points.data())
+        return;
     dev->check(icpx_set_target(dev->ctx(), &cloud->points[0].x, cloud->points.size(), sizeof(Point3f), ICPX_HOST));
-    dev->target_tag = cloud.get();
+    dev->target_ref = cloud; dev->target_n = cloud->points.size(); dev->target_first = cloud->points.data();
     dev->edt_div = 0;
+    dev->edt_owner = nullptr;
 }
 
 static void ensure_edt_on(const DevicePtr& dev, const PointCloudTPtr& cloud, uint32_t div) {
     ensure_target_on(dev, cloud);
-    if (dev->edt_div == div) return;
+    if (dev->edt_div == div && dev->edt_owner == nullptr) return;
     dev->check(icpx_edt_build(dev->ctx(), div));
     dev->edt_div = div;
+    dev->edt_owner = nullptr;
 }
 
 // ---- KDTree ---------------------------------------------------------------------------------------------
@@ -182,7 +188,7 @@ float KDTree::Distance(float x0, float x1, float x2) {
 
 // ---- LDT --------------------------------------------------------------------------------------------------
 
-LDT::LDT(const PointCloudTPtr& cloud, uint32_t _div, int _core, DevicePtr d) : div(_div), CORES(_core), dev(d ? d : std::make_shared<Device>(0)) {
+LDT::LDT(const PointCloudTPtr& cloud, uint32_t _div, int _core, DevicePtr d) : div(_div), CORES(_core), dev(d ? d : std::make_shared<Device>(0)), cloud_(cloud) {
     ensure_edt_on(dev, cloud, div);
     float mn[3];
     dev->check(icpx_edt_info(dev->ctx(), nullptr, mn, &cellLen, &occupied, nullptr));
@@ -190,7 +196,10 @@ LDT::LDT(const PointCloudTPtr& cloud, uint32_t _div, int _core, DevicePtr d) : d
     _max = Point3f(mn[0] + cellLen * div, mn[1] + cellLen * div, mn[2] + cellLen * div);
 }
 
-void LDT::Distance(const float* q, size_t n, float* out) { dev->check(icpx_edt_lookup(dev->ctx(), q, n, ICPX_HOST, out)); }
+void LDT::Distance(const float* q, size_t n, float* out) {
+    ensure_edt_on(dev, cloud_, div);      // another object on the same Device may have changed the target or the grid since
+    dev->check(icpx_edt_lookup(dev->ctx(), q, n, ICPX_HOST, out));
+}
 
 float LDT::Distance(float x, float y, float z) {
     const float q[3] = {x, y, z};
@@ -201,6 +210,7 @@ float LDT::Distance(float x, float y, float z) {
 
 const std::vector<int32_t>& LDT::squared() {
     if (sq_.empty()) {
+        ensure_edt_on(dev, cloud_, div);
         sq_.resize((size_t)div * div * div);
         dev->check(icpx_edt_read(dev->ctx(), sq_.data(), ICPX_HOST));
     }
@@ -244,13 +254,24 @@ void DT3D::Build(const double* x, const double* y, const double* z, int num) {
     cloud_ = std::make_shared<PointCloudT>();
     cloud_->points.resize((size_t)num);
     for (int i = 0; i < num; i++) cloud_->points[i] = Point3f((float)x[i], (float)y[i], (float)z[i]);
+    ensure_grid();
+}
+
+// The context's grid is this object's (rounded voxel rule, this box): built now if another object has used the Device since.
+void DT3D::ensure_grid() {
+    if (!cloud_) throw IcpxFailure(ICPX_ESTATE, "DT3D::Distance before Build");
     ensure_target_on(dev, cloud_);
+    if (dev->edt_owner == this) return;
     const double mn[3] = {xMin, yMin, zMin};
     dev->check(icpx_edt_build_round(dev->ctx(), (uint32_t)SIZE, mn, scale));
     dev->edt_div = 0;   // the context's grid no longer follows LDT's box rule
+    dev->edt_owner = this;
 }
 
-void DT3D::Distance(const double* xyz, size_t n, float* out) { dev->check(icpx_edt_lookup_round(dev->ctx(), xyz, n, ICPX_HOST, out)); }
+void DT3D::Distance(const double* xyz, size_t n, float* out) {
+    ensure_grid();
+    dev->check(icpx_edt_lookup_round(dev->ctx(), xyz, n, ICPX_HOST, out));
+}
 
 float DT3D::Distance(double x, double y, double z) {
     const double q[3] = {x, y, z};
@@ -389,7 +410,7 @@ void SingleThreadIcp::cal_covarance() {
     const double denom = (double)(float)Nd_global;   // "/= (float)Nd", :244
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) Neighbour.covariance(r, c) = (sums_[6 + 3 * r + c] - mean_tmpdata[r] * sums_[3 + c]) / denom;
-    mse_trace.push_back(sums_[15] / N);
+    nn_mse_trace.push_back(sums_[15] / N);
 }
 
 Matrix4d& SingleThreadIcp::best_fit_transform() {
@@ -400,6 +421,20 @@ Matrix4d& SingleThreadIcp::best_fit_transform() {
         T(r, 3) = mean_tar[r] - (R(r, 0) * mean_tmpdata[0] + R(r, 1) * mean_tmpdata[1] + R(r, 2) * mean_tmpdata[2]);
     }
     T_trace.push_back(T);
+    // The residual the reference logs after applying T with the pairs it was fitted to ("each transform mse",
+    // src/SingleThreadIcp.cpp:281-288): sum |R p + t - q|^2 / Nd, from the same sums:
+    //   sum |Rp + t - q|^2 = sum |p - q|^2 + 2 tr(Spq) + N |t|^2 + 2 t.(R Sp) - 2 sum_ij R_ij Spq_ji - 2 t.Sq.
+    {
+        const double N = (double)Nd_global;
+        const double* Sp = sums_; const double* Sq = sums_ + 3; const double* Spq = sums_ + 6;
+        double tr = Spq[0] + Spq[4] + Spq[8], tt = 0, tRSp = 0, RS = 0, tSq = 0;
+        for (int i = 0; i < 3; i++) {
+            tt += T(i, 3) * T(i, 3);
+            tSq += T(i, 3) * Sq[i];
+            for (int j = 0; j < 3; j++) { tRSp += T(i, 3) * R(i, j) * Sp[j]; RS += R(i, j) * Spq[3 * j + i]; }
+        }
+        mse_trace.push_back((sums_[15] + 2 * tr + N * tt + 2 * tRSp - 2 * RS - 2 * tSq) / N);
+    }
     return T;
 }
 
@@ -407,6 +442,7 @@ ICP_res SingleThreadIcp::registration(Matrix4d& guess, const PointCloudTPtr& pDa
     if (pData.get() != source.get() || Nd != (int)pData->points.size()) setSource(pData);
     finMat = guess;
     mse_trace.clear();
+    nn_mse_trace.clear();
     T_trace.clear();
     for (int iter = 0; iter < max_iter; iter++) {
         kdtree_search();
@@ -471,11 +507,26 @@ void GoIcp::clear() {
     maxRotDist = nullptr;
 }
 
+// d_i = dt.Distance((float)(M x_i)) for every data point: the exact nearest-neighbour distance (KDTree::Distance, what
+// the committed reference's `KDTree dt` returns, src/GoIcp.cpp:76-77) or the distance-transform lookup (LDT::Distance).
+void GoIcp::residuals(const Matrix4d& M, float* dist) {
+    if (!exact_residuals) { dev->check(icpx_goicp_residuals(dev->ctx(), M.m, dist)); return; }
+    std::vector<float> q((size_t)Nd * 3);
+    for (int i = 0; i < Nd; i++) {
+        const Point3f& s = pData->points[i];
+        const double p[3] = {(double)s.x, (double)s.y, (double)s.z};
+        double o[3];
+        apply4(M, p, o);
+        q[3 * (size_t)i] = (float)o[0]; q[3 * (size_t)i + 1] = (float)o[1]; q[3 * (size_t)i + 2] = (float)o[2];
+    }
+    dev->check(icpx_nn_distance(dev->ctx(), q.data(), (size_t)Nd, ICPX_HOST, dist));
+}
+
 float GoIcp::runICP(Matrix4d& tmpMat) {
     ICP_res r = icp.registration(tmpMat, pData);
     tmpMat = r.transMat;
     std::vector<float> dist(Nd);
-    dev->check(icpx_goicp_residuals(dev->ctx(), tmpMat.m, dist.data()));
+    residuals(tmpMat, dist.data());
     float SSE = 0.0f;
     for (int i = 0; i < Nd; i++) SSE += dist[i] * dist[i];   // error[i] = dis*dis, then a float sum (:127, :133-135)
     return SSE;
@@ -704,7 +755,7 @@ float GoIcp::OuterBnB() {
     // initial error: identity pose, sequential float sum (src/GoIcp.cpp:159-172)
     {
         Matrix4d I = Matrix4d::Identity();
-        dev->check(icpx_goicp_residuals(dev->ctx(), I.m, minDis.data()));
+        residuals(I, minDis.data());
         optError = 0;
         for (int i = 0; i < Nd; i++) optError += minDis[i] * minDis[i];
         initError = optError;
@@ -791,8 +842,9 @@ float GoIcp::OuterBnB() {
                 prepare(parent, *cur);
                 for (Search& s : cur->ss) run.push_back(&s);
             }
-            // the cubes most likely to be popped next: the best of the queue as it stands
-            if (speculate > 0) {
+            // With them, in the same launches, the cubes most likely to be popped next: the best of the queue as it
+            // stands. Only when a search has to run anyway: a cube found searched already costs no launch at all.
+            if (speculate > 0 && !run.empty()) {
                 const std::vector<RotNode>& h = rq.heap();
                 std::vector<size_t> cand;
                 if (!h.empty()) cand.push_back(0);
@@ -1012,8 +1064,10 @@ int icpxh_icp_set_collective(void* p, int rank, int world, void (*allreduce)(dou
         h->icp->setSource(h->src);   // refresh Nd_global
     });
 }
-// guess16 / T_out16 row-major; per_iter_T (iters x 16), mse (iters) and resN3 (ns x 3) may be NULL.
-int icpxh_icp_registration(void* p, const double* guess16, double* T_out16, double* per_iter_T, double* mse, double* resN3, int32_t* idx_last) {
+// guess16 / T_out16 row-major; per_iter_T (iters x 16), mse (iters: the NN residual before each update), mse_after (iters: the
+// residual the reference logs after each update) and resN3 (ns x 3) may be NULL.
+int icpxh_icp_registration(void* p, const double* guess16, double* T_out16, double* per_iter_T, double* mse, double* resN3, int32_t* idx_last,
+                           double* mse_after) {
     return guard([&] {
         HIcp* h = (HIcp*)p;
         Matrix4d g;
@@ -1023,7 +1077,8 @@ int icpxh_icp_registration(void* p, const double* guess16, double* T_out16, doub
         std::memcpy(T_out16, r.transMat.m, sizeof r.transMat.m);
         const int it = h->icp->max_iter;
         if (per_iter_T) for (int k = 0; k < it; k++) std::memcpy(per_iter_T + 16 * k, h->icp->T_trace[k].m, 16 * sizeof(double));
-        if (mse) for (int k = 0; k < it; k++) mse[k] = h->icp->mse_trace[k];
+        if (mse) for (int k = 0; k < it; k++) mse[k] = h->icp->nn_mse_trace[k];
+        if (mse_after) for (int k = 0; k < it; k++) mse_after[k] = h->icp->mse_trace[k];
         if (resN3) std::memcpy(resN3, r.resN3.data.data(), r.resN3.data.size() * sizeof(double));
         if (idx_last) std::memcpy(idx_last, h->icp->Neighbour.pointsPARA.data(), sizeof(int32_t) * h->icp->Nd);
     });
@@ -1095,6 +1150,7 @@ int icpxh_goicp_options(void* p, int run_bnb, int batched, int parity_sums, int 
     h->go->speculate = speculate;
     return 0;
 }
+int icpxh_goicp_exact_residuals(void* p, int on) { ((HGo*)p)->go->exact_residuals = on != 0; return 0; }
 // Device-side collective: allreduce_dev sums n doubles at a device address inside [dev_buffer, dev_buffer + capacity) over
 // the ranks, in place, on the stream given here (which the context then uses for everything).
 int icpxh_goicp_set_collective_dev(void* p, int rank, int world, void (*allreduce_dev)(double*, int), double* dev_buffer,

@@ -88,8 +88,14 @@ public:
     Device& operator=(const Device&) = delete;
     icpx_ctx* ctx() const { return ctx_; }
     void check(int rc) const;   // throws IcpxFailure with icpx_last_error
-    const void* target_tag = nullptr;   // identity of the cloud last given to icpx_set_target
-    uint32_t edt_div = 0;               // resolution of the EDT built for that target (0 = none)
+    // the cloud last given to icpx_set_target: the object (weak, so a dead cloud's address is never mistaken for a new
+    // cloud's), its size and its storage
+    std::weak_ptr<struct PointCloudT> target_ref;
+    size_t target_n = 0;
+    const void* target_first = nullptr;
+    void forget_target() { target_ref.reset(); target_n = 0; target_first = nullptr; edt_div = 0; edt_owner = nullptr; }
+    uint32_t edt_div = 0;               // resolution of the EDT built for that target by LDT's box rule (0 = none)
+    const void* edt_owner = nullptr;    // the DT3D object whose grid the context holds instead (nullptr: none)
 private:
     icpx_ctx* ctx_ = nullptr;
 };
@@ -144,6 +150,7 @@ public:
     uint64_t occupied = 0;
     DevicePtr dev;
 private:
+    PointCloudTPtr cloud_;
     std::vector<int32_t> sq_;
     std::vector<float> g_;
 };
@@ -164,6 +171,7 @@ public:
     DevicePtr dev;
 private:
     PointCloudTPtr cloud_;
+    void ensure_grid();
 };
 
 struct Correspondance {     // src/SingleThreadIcp.cpp:37-44
@@ -191,7 +199,8 @@ public:
     Matrix4d finMat;               // accumulated transform applied to the source on the GPU
     Vector3d mean_tar, mean_tmpdata;
     bool keep_correspondences = false;   // fill Neighbour.pointsPARA every iteration (costs a device->host copy)
-    std::vector<double> mse_trace;       // sum |p - q|^2 / Nd BEFORE each update (the NN residual)
+    std::vector<double> mse_trace;       // per iteration, sum |T p - q|^2 / Nd AFTER the update with the pairs it was fitted to: the value the reference logs (src/SingleThreadIcp.cpp:281-288)
+    std::vector<double> nn_mse_trace;    // per iteration, sum |p - q|^2 / Nd BEFORE the update (the NN residual)
     std::vector<Matrix4d> T_trace;       // per-iteration T
     Collective comm;                     // world > 1: this object holds one slice of the source
     long long Nd_global = 0;             // total source points over all ranks (= Nd when world == 1)
@@ -272,6 +281,11 @@ public:
     bool run_bnb = true;          // false: stop after the initial ICP, like the committed early return (src/GoIcp.cpp:189)
     bool batched = true;          // true: the 2 x 8 inner searches of one rotation parent advance in lock-step, one launch per step
     bool parity_sums = false;     // true: bounds are the reference's sequential float sums of the per-point distances
+    // The committed reference declares `// LDT dt; KDTree dt;` (src/GoIcp.cpp:76-77): its initial error (:164) and the SSE
+    // after an ICP (:125) are sums of EXACT nearest-neighbour distances. true reproduces that (icpx_nn_distance); false, the
+    // default, takes them from the distance transform like the bounds, which is what Go-ICP itself does and keeps errors
+    // and bounds comparable when the rotation search runs (they differ from the exact ones by at most sqrt(3) cells per point).
+    bool exact_residuals = false;
     // Translation parents popped per inner search and step (batched mode). The reference's inner search returns at
     // the first evaluated child whose lower bound is within sseThresh of the best error (src/GoIcp.cpp:445-449), so
     // the expansion order decides where it stops: 1 keeps the reference's order, larger values are faster per cube
@@ -300,6 +314,7 @@ public:
 private:
     struct Search;
     float R_[9];                                   // rotation of the current cube (innerBnB operates on it)
+    void residuals(const Matrix4d& M, float* dist);
     int cur_level_of(const float* maxDistL) const;
     void eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub, std::vector<float>& lb);
     void run_searches(const std::vector<Search*>& ss);

@@ -860,7 +860,10 @@ int icpx_grid_build(icpx_ctx* ctx) {
     double vol = 1.0;
     for (int c = 0; c < 3; c++) vol *= std::max(ext[c], floor_e);
     double h = std::cbrt(vol / (double)n);
-    const double max_cells = 3.2e7;
+    // At most 1024 cells per axis (the walk packs node coordinates in ten bits), so at most 2^30 cells: 4 GiB each for the
+    // counts and the starts, reached only by clouds of ten million points and more (16 M surface points: 1024^3 cells, about
+    // six points per occupied cell; a cap of 3.2e7 cells left 65 per cell there and every query to the pyramid walk).
+    const double max_cells = 1.08e9;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     ICPX_TRY(icpx_sort_reserve(ctx, n));
     ICPX_TRY(icpx_reserve(ctx, ctx->scratch_q, n * sizeof(float4)));

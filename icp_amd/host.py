@@ -32,7 +32,7 @@ def _lib():
         lib.icpxh_ldt_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.icpxh_ldt_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.icpxh_icp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
-        lib.icpxh_icp_registration.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        lib.icpxh_icp_registration.argtypes = [C.c_void_p] + [C.c_void_p] * 7
         lib.icpxh_dt3d_new.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]
         lib.icpxh_dt3d_free.argtypes = [C.c_void_p]; lib.icpxh_dt3d_free.restype = None
         lib.icpxh_dt3d_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -41,6 +41,7 @@ def _lib():
         lib.icpxh_icp3d_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_int,
                                         C.c_double, C.c_void_p, C.c_void_p]
         lib.icpxh_goicp_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int]
+        lib.icpxh_goicp_exact_residuals.argtypes = [C.c_void_p, C.c_int]
         lib.icpxh_goicp_set_collective_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.icpxh_goicp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
         lib.icpxh_goicp_registration.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -186,8 +187,9 @@ class SingleThreadIcp:
         T = np.empty(16); per = np.empty((self.iters, 16)); mse = np.empty(self.iters)
         res = np.empty((self._s.shape[0], 3)) if want_points else None
         idx = np.empty(self._s.shape[0], np.int32) if want_idx else None
-        _ck(_lib().icpxh_icp_registration(self._h, _vp(g), _vp(T), _vp(per), _vp(mse), _vp(res), _vp(idx)))
-        return dict(T=T.reshape(4, 4), per_iter_T=per.reshape(-1, 4, 4), nn_mse=mse, resN3=res, idx_last=idx)
+        after = np.empty(self.iters)
+        _ck(_lib().icpxh_icp_registration(self._h, _vp(g), _vp(T), _vp(per), _vp(mse), _vp(res), _vp(idx), _vp(after)))
+        return dict(T=T.reshape(4, 4), per_iter_T=per.reshape(-1, 4, 4), nn_mse=mse, mse=after, resN3=res, idx_last=idx)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -260,8 +262,10 @@ class GoIcp:
             self._cb = make_allreduce(allreduce)
             _ck(_lib().icpxh_goicp_set_collective(self._h, rank, world, self._cb))
 
-    def options(self, run_bnb=True, batched=True, parity_sums=False, frontier_width=1, max_rot_pops=0, lookahead=4, speculate=0):
+    def options(self, run_bnb=True, batched=True, parity_sums=False, frontier_width=1, max_rot_pops=0, lookahead=4, speculate=0,
+                exact_residuals=False):
         _ck(_lib().icpxh_goicp_options(self._h, int(run_bnb), int(batched), int(parity_sums), frontier_width, max_rot_pops, lookahead, speculate))
+        _lib().icpxh_goicp_exact_residuals(self._h, int(exact_residuals))
         return self
 
     def registration(self, want_points=False):

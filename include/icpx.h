@@ -97,7 +97,8 @@ int icpx_set_source(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_byt
 /* One pass of the hot loop of SingleThreadIcp::registration (src/SingleThreadIcp.cpp:307-316):
  * p_i = T * [src_i; 1] in double (T = row-major 4x4, host memory, the ACCUMULATED transform
  * finMat), q_i = nearest target point of p_i (kdtree_search, :186-214), and the sums that
- * cal_covarance (:216-247) and the residual log of best_fit_transform (:281-287) need:
+ * cal_covarance (:216-247) needs, and from which the residual that best_fit_transform logs after its update (:281-287)
+ * follows without another pass over the points (icp::SingleThreadIcp::best_fit_transform has the formula):
  *   sums[0..2] = sum p, sums[3..5] = sum q, sums[6..14] = sum p q^T, sums[15] = sum |p - q|^2.
  * The caller forms the means, H = (sum p q^T - pbar (sum q)^T) / n, and runs the 3x3 SVD on the host.
  * sums: 16 doubles of host memory. idx_opt: NULL, or n int32 (memory kind `idx_where`) receiving the
@@ -223,7 +224,10 @@ int icpx_bnb_eval_noalloc(icpx_ctx* ctx, const icpx_bnb_item* items_dev, size_t 
 
 /* Replaces the SSE loop of GoIcp::runICP (src/GoIcp.cpp:113-135) and the initial error of OuterBnB
  * (:161-172): d_i = Distance((float)(T * [x_i;1])) for the data cloud, T row-major 4x4 double (host);
- * writes every d_i (n floats, host, caller's order) so the caller can form the sequential float sum. */
+ * writes every d_i (n floats, host, caller's order) so the caller can form the sequential float sum.
+ * Distance here is LDT::Distance on the context's distance transform. The committed reference instantiates its `dt`
+ * member as a KDTree (src/GoIcp.cpp:76-77), i.e. sums exact nearest-neighbour distances: icpx_nn_distance on the
+ * transformed points gives those (icp::GoIcp::exact_residuals does that). */
 int icpx_goicp_residuals(icpx_ctx* ctx, const double T[16], float* dist_out);
 
 #ifdef __cplusplus

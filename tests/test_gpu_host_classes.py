@@ -52,7 +52,14 @@ def test_icp_bunny_30_iterations(oracle, bunny000, bunny045):
     assert np.abs(got["T"] - ref["T"]).max() < 1e-11
     row0 = [0.8447934139625265, 0.026791961891060055, -0.53442144278048831, 0.035047392296106809]
     assert np.abs(got["T"][0] - row0).max() < 1e-11
-    assert np.array_equal(got["idx_last"], oracle.icp(bunny000, bunny045, 30, nn_mode=1)["idx_last"])
+    low = oracle.icp(bunny000, bunny045, 30, nn_mode=1)                # lowest-index ties, like the GPU
+    assert np.array_equal(got["idx_last"], low["idx_last"])
+    # the residual the reference logs per iteration ("each transform mse": after the update, with the pairs it was fitted
+    # to), here from the 16 sums alone; the oracle sums float-rounded terms, hence 1e-6 relative. First and last values as
+    # recorded from a run of the reference: 3.862e-4, 9.561e-6.
+    np.testing.assert_allclose(got["mse"], low["mse"], rtol=2e-6)
+    assert abs(got["mse"][0] - 3.862e-4) < 1e-7 and abs(got["mse"][-1] - 9.561e-6) < 1e-9
+    assert np.all(got["mse"] <= got["nn_mse"] * (1 + 1e-12))          # the fitted transform cannot increase the residual of its pairs
     p = bunny000.astype(np.float64) @ got["T"][:3, :3].T + got["T"][:3, 3]
     assert np.abs(got["resN3"] - p).max() < 1e-12
     # a second call continues from the carried target mean exactly like the oracle's state does not:
@@ -129,6 +136,12 @@ def test_goicp_as_committed(oracle, bunny000, bun270):
     got = go.registration()
     ldt = LDT(model, 300); _, sq = ldt.grids()
     ref = oracle.goicp(model, data, 1e-3, run_bnb=False, dist_mode=1, sq=sq, mn=ldt._min, cell=ldt.cellLen)
+    assert got["initError"] == ref["initError"]
+    assert abs(float(got["icpError"]) - float(ref["icpError"])) <= 1e-6 * float(ref["icpError"])
+    assert np.abs(got["optMat"] - ref["optMat"]).max() < 1e-9
+    # as the committed code has it: `KDTree dt` (src/GoIcp.cpp:76-77), exact nearest-neighbour distances in both sums
+    got = GoIcp(model, data, mse=1e-3, dt_div=300).options(run_bnb=False, exact_residuals=True).registration()
+    ref = oracle.goicp(model, data, 1e-3, run_bnb=False, dist_mode=0)
     assert got["initError"] == ref["initError"]
     assert abs(float(got["icpError"]) - float(ref["icpError"])) <= 1e-6 * float(ref["icpError"])
     assert np.abs(got["optMat"] - ref["optMat"]).max() < 1e-9
@@ -220,6 +233,11 @@ def test_goicp_bunny270_against_oracle_golden(bunny000, bun270):
         assert float(r["initError"]) == gold["initError"]
         assert abs(float(r["icpError"]) - gold["icpError"]) <= 1e-6 * gold["icpError"]
         assert float(r["optError"]) - r["lb"] < r["sseThresh"]          # certificate
+    # the reference's own order (one inner search after the other, sequential float sums; at full size it reaches the
+    # same optimum and the same 7 423 rotation cubes as the lock-step search, profiles/r02_goicp_strict_full.log)
+    rs = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=False, parity_sums=True).registration()
+    assert abs(float(rs["optError"]) - gold["optError"]) <= 1e-6 * gold["optError"] and rs["rot_pops"] == gold["rot_pops"]
+    assert abs(rs["lb"] - gold["lb"]) <= 1e-6 * gold["lb"]      # (inner_evals also counts the bounds evaluated ahead of time, so it is not compared)
     # bounds evaluated ahead of time change neither a decision nor the result of the reference's order: the same
     # rotation cubes, bit-identical optimum and lower bound, in fewer launches
     r1 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=0).registration()

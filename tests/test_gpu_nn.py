@@ -182,3 +182,37 @@ def test_knn_small_cloud_and_limits(gpu_ctx, oracle):
         gpu_ctx.knn(q, 9)
     with pytest.raises(IcpxError):
         gpu_ctx.knn(q, 0)
+
+
+def test_nn_sixteen_million_target(oracle):
+    """The large scan-to-model case (16 M target points, the size the reference's kd-tree cannot hold: its arrays end at
+    1e6 + 10 points, src/kdtree.cpp:13): grid build at that size, sampled queries — near the surface, far from it, outside the
+    box — against brute force, bit for bit; then one fused ICP pass over 2 M source points, sampled pairs against brute force."""
+    from icp_amd.api import Context
+    n = 16_000_000
+    tgt = synth_surface(n, 44)
+    rng = np.random.default_rng(6)
+    near = synth_surface(1200, 45, noise=1e-3).astype(np.float64)
+    far = rng.uniform(-0.6, 0.6, (500, 3))
+    q = np.ascontiguousarray(np.concatenate([near, far, tgt[:300].astype(np.float64)]))
+    ctx = Context(0)
+    try:
+        ctx.set_target(tgt)
+        idx, d2 = ctx.nn(q)
+        ridx, rd2 = oracle.nn_brute(q, tgt)
+        assert np.array_equal(d2, rd2) and np.array_equal(idx, ridx)
+        Tm = rigid([1, 1, 1], 10.0, [0.02, -0.01, 0.015])
+        src = synth_surface(2_000_000, 45, noise=1e-3)
+        ctx.set_source(src)
+        for T in (Tm, np.eye(4)):                      # far first, then on the surface with the previous pairs to start from
+            sums, idx = ctx.icp_step(T, want_idx=True)
+            pick = rng.choice(src.shape[0], 1500, replace=False)
+            s = src[pick].astype(np.float64)
+            p = np.empty_like(s)
+            for r in range(3):
+                p[:, r] = ((0.0 + T[r, 0] * s[:, 0]) + T[r, 1] * s[:, 1]) + T[r, 2] * s[:, 2] + T[r, 3]
+            ridx, rd2 = oracle.nn_brute(np.ascontiguousarray(p), tgt)
+            assert np.array_equal(idx[pick], ridx)
+            assert idx.min() >= 0 and idx.max() < n and np.isfinite(sums).all()
+    finally:
+        ctx.close()
