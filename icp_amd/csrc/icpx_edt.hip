@@ -17,6 +17,7 @@
 // Memory traffic: the only full-size arrays are the in-plane distances (written for non-empty planes,
 // read once) and the output; the occupancy is 1 bit per voxel and stays in L2.
 // How the envelope scans are organised: see "lower envelope of parabolas" below.
+#include <type_traits>
 #include <hip/hip_ext.h>
 
 #include "icpx_ctx.h"
@@ -288,9 +289,11 @@ __device__ __forceinline__ unsigned lds_address(const void* p) {
 
 template <int G, bool POOL>
 __device__ __forceinline__ void env_init(const Env<G, POOL>& E, int g, EnvTop& e) {
-    e = EnvTop{-1, 0u, 0, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu, -1, 0u, 0u};
+    // Without the pool a sentinel entry sits below level 0 and is what an empty stack holds as its top: site 0 with
+    // the largest value there is, from position 0.
+    e = EnvTop{-1, POOL ? 0u : ENV_VMASK, 0, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu, -1, 0u, 0u};
     e.aw = lds_address(E.lds + e.wb - 256); e.at = lds_address(E.lds + e.tb - 128);
-    if (!POOL) { E.W(e.wb, -1) = 0u; E.T(e.tb, -1) = 0; }   // the sentinel below level 0
+    if (!POOL) { E.W(e.wb, -1) = ENV_VMASK; E.T(e.tb, -1) = 0; }
 }
 
 // Adds site u (ascending) with value v to the stack of group g: pop while the new parabola is lower at
@@ -299,7 +302,9 @@ __device__ __forceinline__ void env_init(const Env<G, POOL>& E, int g, EnvTop& e
 // f(p) = p^2 - 2 p s + a, so "new lower than top at t" is 2 t (u - s) + (a_top - a_u) > 0 and the
 // crossing is (a_u - a_top) / (2 (u - s)); entries carry a instead of v. Reads below the bottom of a
 // stack return whatever precedes it in LDS and are never used.
-template <int G, bool POOL>
+// SAFE (hand-written variant only): the stack cannot outgrow its levels (the group has no more sites than levels),
+// so the level needs no clamp and the deepest level is not tracked.
+template <int G, bool POOL, bool SAFE = false>
 __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e, int u, int v, int div) {
     const int au = (u & 0x3ff) * (u & 0x3ff) + v;
     int d, dd, w;
@@ -308,7 +313,6 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
         // predicated instead of divergent (lanes that are done re-read the entry they already hold): 18
         // instructions per round where the compiled divergent loop needs about 30, most of them mask
         // bookkeeping, and a wave issues one instruction every eight cycles or so whatever its kind. The
-        // sentinel row makes "stack empty" a case of the same test: 0 * d + (0 - au) > 0 is false. The
         // push follows as straight-line selects. The compiler does not see the LDS traffic in here: the wait for
         // the loop's last read-back sits behind the crossing's arithmetic, which covers most of its latency,
         // and the writes need none (LDS operations of a wave complete in order).
@@ -320,9 +324,8 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
             "v_sub_u32 %[d], %[u], %[d]\n"
             "v_sub_u32 %[dd], %[dd], %[au]\n"
             "v_mad_i32_i24 %[x], %[tt2], %[d], %[dd]\n"
-            // pop while x > 0 and q >= 0, i.e. min(x, q + 1) > 0. With sane input the sentinel already fails x > 0;
-            // the second condition ends the loop whatever the input (pass x also runs on what an overflowed pass
-            // zy left behind, before the build is repeated: values there can be anything, negative included)
+            // pop while x > 0 and q >= 0, i.e. min(x, q + 1) > 0: the second condition stops at the sentinel,
+            // whatever the input
             "v_add_u32 %[y], 1, %[q]\n"
             "v_min_i32 %[x], %[x], %[y]\n"
             "v_cmp_lt_i32 vcc, 0, %[x]\n"
@@ -347,9 +350,11 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
             "v_mul_f32 %[x], %[x], %[y]\n"
             "v_cvt_i32_f32 %[x], %[x]\n"
             "v_add_u32 %[w], 1, %[x]\n"
-            // an empty stack takes the site from position 0; the site enters if its first position is inside the row
-            "v_cmp_gt_i32 vcc, 0, %[q]\n"
-            "v_cndmask_b32_e64 %[w], %[w], 0, vcc\n"
+            // Against the sentinel the quotient is below -500 for every site there can be (the sentinel's value exceeds
+            // any site's by more than a million, the divisor is at most 4 * 1022; u = 0 gives -inf, converted to the
+            // most negative integer): an empty stack takes the site from position 0 by this clamp alone. Real
+            // entries cross at positive positions. The site enters if its first position is inside the row.
+            "v_max_i32 %[w], 0, %[w]\n"
             "v_lshl_or_b32 %[x], %[u], 22, %[au]\n"
             "v_lshlrev_b32 %[y], 1, %[w]\n"
             "v_cmp_gt_i32 vcc, %[div], %[w]\n"
@@ -359,17 +364,23 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
             "v_cndmask_b32 %[tw], %[tw], %[x], vcc\n"
             "v_cndmask_b32 %[tt2], %[tt2], %[y], vcc\n"
             "v_addc_co_u32 %[q], vcc, 0, %[q], vcc\n"
+            // every lane writes its top entry (lanes that did not push rewrite what is there); unless the stack is
+            // known to fit, the level is clamped to the last private one and a stack that got there is reported by
+            // env_finish
+            ".if %c[safe] == 0\n"
             "v_max_i32 %[deep], %[deep], %[q]\n"
-            // every lane writes its top entry (lanes that did not push rewrite what is there); the level is
-            // clamped to the last private one, a stack that got there is reported by env_finish
             "v_min_i32 %[d], %[capm1], %[q]\n"
             "v_lshl_add_u32 %[dd], %[d], 8, %[aw]\n"
             "v_lshl_add_u32 %[d], %[d], 7, %[at]\n"
+            ".else\n"
+            "v_lshl_add_u32 %[dd], %[q], 8, %[aw]\n"
+            "v_lshl_add_u32 %[d], %[q], 7, %[at]\n"
+            ".endif\n"
             "ds_write_b32 %[dd], %[tw] offset:256\n"
             "ds_write_b16 %[d], %[tt2] offset:128\n"
             : [tw] "+v"(e.tw), [tt2] "+v"(e.tt2), [bw] "+v"(e.bw), [bt2] "+v"(e.bt2), [q] "+v"(e.q), [deep] "+v"(e.deepest),
               [d] "=&v"(d), [dd] "=&v"(dd), [x] "=&v"(x), [y] "=&v"(y), [w] "=&v"(w)
-            : [u] "s"(u), [au] "v"(au), [aw] "v"(e.aw), [at] "v"(e.at), [div] "s"(div), [capm1] "s"(E.cap - 1)
+            : [u] "s"(u), [au] "v"(au), [aw] "v"(e.aw), [at] "v"(e.at), [div] "s"(div), [capm1] "s"(E.cap - 1), [safe] "n"(SAFE ? 1 : 0)
             : "vcc", "memory");
         return;
     } else {
@@ -405,6 +416,20 @@ __device__ __forceinline__ void env_finish(const Env<G, POOL>& E, int g, EnvTop&
     if (POOL) E.table(g) = e.tab;
 }
 
+// A wave's 64 lanes read or write one 256-byte piece of a grid row: base (the same in all lanes) + 4 * lane_off,
+// lane_off < 64. As a buffer access the base stays in scalar registers and is advanced by scalar instructions; as a
+// flat pointer the compiler keeps a 64-bit address per lane and spends vector instructions on it at every step.
+// Accesses beyond the 256 bytes would be dropped by the range check; there are none.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_piece(const int* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(base), 0, 256, 0x00020000);
+}
+__device__ __forceinline__ void row_store(int* base, unsigned lane_off, int v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, row_piece(base), (int)(lane_off * 4u), 0, 0);
+}
+__device__ __forceinline__ int row_load(const int* base, unsigned lane_off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(row_piece(base), (int)(lane_off * 4u), 0, 0);
+}
+
 // Evaluation cursor on one stack, walking towards position 0.
 struct EnvCur {
     int lvl;                // level of the current entry
@@ -432,7 +457,9 @@ __device__ __forceinline__ void env_seek(const Env<G, POOL>& E, int j, EnvCur& c
 
 // f(p) - p^2 of the entry under the cursor: a 24-bit multiply-add
 __device__ __forceinline__ int env_value(const EnvCur& c, int p) {
-    return __mul24((int)(c.cw >> ENV_VB), -2 * p) + (int)(c.cw & ENV_VMASK);   // 0 <= p <= 1022
+    // cw = s * 2^22 + a, so a - 2 p s = cw - s (2^22 + 2 p) in 32-bit arithmetic: no mask needed (0 <= p <= 1022, the
+    // multiplier stays inside 24 bits)
+    return (int)((unsigned)__mul24((int)(c.cw >> ENV_VB), -(2 * p + (1 << ENV_VB))) + c.cw);
 }
 
 // One level down if p was the first position of the current entry. The entry below is already in
@@ -461,7 +488,7 @@ __device__ __forceinline__ void env_span(const Env<G, POOL>& E, EnvCur (&cur)[G]
         int v = 0x7fffffff;
 #pragma unroll
         for (int j = LO; j < LO + N; j++) v = min(v, env_value(cur[j], p));
-        (out + (size_t)p * stride)[lane_off] = v + p * p;   // idle lanes shadow the last row: same value, same address
+        row_store(out + (size_t)p * stride, lane_off, v + p * p);   // idle lanes shadow the last row: same value, same address
 #pragma unroll
         for (int j = LO; j < LO + N; j++) {   // only the stacks that are still above pay for the general read-back
             if (__any(cur[j].lvl >= E.cap)) env_step<G, POOL, true>(E, j, cur[j], p);
@@ -474,7 +501,7 @@ __device__ __forceinline__ void env_span(const Env<G, POOL>& E, EnvCur (&cur)[G]
         int v = 0x7fffffff;
 #pragma unroll
         for (int j = LO; j < LO + N; j++) v = min(v, env_value(cur[j], p));
-        (out + (size_t)p * stride)[lane_off] = v + p * p;   // idle lanes shadow the last row: same value, same address
+        row_store(out + (size_t)p * stride, lane_off, v + p * p);   // idle lanes shadow the last row: same value, same address
 #pragma unroll
         for (int j = LO; j < LO + N; j++) env_step<G, POOL, false>(E, j, cur[j], p);
     }
@@ -586,7 +613,8 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_zy(const RowRec* __res
     if (cnt == 0) return;   // plane without voxels: never read by pass x
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int z = min(c * 64 + lane, div - 1);   // lanes beyond the row's end shadow its last voxel: same work, same stores
-    const int zl = z & 63;
+    const int zl = z & 63;   // the lane's offset inside the chunk: addresses are (uniform base) + 4 zl, which lets the
+                             // loads and stores take their base from scalar registers
     const Env<G, POOL> E = env_setup<G, POOL>(lds, G * RB, cap, nch, lane, spill_buf, div, (size_t)div * div, (size_t)x * div + z, &counters[4]);
 
     if (g < G) {
@@ -595,6 +623,7 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_zy(const RowRec* __res
         EnvTop e;
         env_init(E, g, e);
         int4 nxt = klo + lane < khi ? rr4[klo + lane] : make_int4(0, 0, 0, 0);
+        auto scan = [&](auto safe) {
         for (int k0 = klo; k0 < khi; k0 += 64) {
             const int4 cur = nxt;
             if (k0 + 64 + lane < khi) nxt = rr4[k0 + 64 + lane];
@@ -614,13 +643,16 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_zy(const RowRec* __res
                     if (md) gd = min(gd, zl - (63 - __clzll(md)));   // a voxel inside the chunk is nearer than any beyond it on its side
                     if (mu) gd = min(gd, __ffsll((long long)mu) - 1);
                 }
-                env_add(E, g, e, u, __mul24(gd, gd), div);
+                env_add<G, POOL, decltype(safe)::value>(E, g, e, u, __mul24(gd, gd), div);
             }
         }
+        };
+        // a group with no more sites than levels cannot overflow its stack: the cheaper site step
+        if (!POOL && !report && khi - klo <= cap) scan(std::true_type{}); else scan(std::false_type{});
         env_finish(E, g, e, e.deepest + 1, report ? &counters[3] : nullptr);
     }
     __syncthreads();
-    env_write(E, g, G * RB, plane + (size_t)x * div * div, (size_t)div, (unsigned)z, div);
+    env_write(E, g, G * RB, plane + (size_t)x * div * div + c * 64, (size_t)div, (unsigned)zl & 63u, div);
 }
 
 // ---- pass x ---------------------------------------------------------------------------------------------
@@ -646,6 +678,9 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restric
     // XCD the same one or two z chunks of all rows, and the chunks differ a lot in work (bunny, 1008^3: 2.63 ms
     // against 1.87 ms with the chunks rotated by row). Other counts rotate by themselves; at 300^3 (5 chunks) the
     // rotation costs 2 us, so it is applied only where it is needed.
+    // pass zy overflowed its stacks: the plane values are not all written, the build is repeated with other shapes
+    // anyway, and nothing this pass could compute from them would be used
+    if (counters[4] != 0) return;
     const int y = blockIdx.x / nchunk;
     int c = blockIdx.x % nchunk;
     if ((nchunk & 7) == 0) c = (c + y) % nchunk;
@@ -654,6 +689,8 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restric
     const int np = (int)counters[2];
     const size_t xs = (size_t)div * div;                  // elements between consecutive x
     const int rowoff = y * div + z;
+    const size_t rowbase = (size_t)y * div + c * 64;   // uniform part of rowoff
+    const unsigned zl = (unsigned)(z - c * 64) & 63u;   // the lane's part
     const Env<G, POOL> E = env_setup<G, POOL>(lds, G * RB, cap, nch, lane, spill_buf, div, xs, (size_t)rowoff, &counters[5]);
 
     if (g < G) {
@@ -664,7 +701,8 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restric
     #pragma unroll
         for (int j = 0; j < PF; j++) Un[j] = planelist[klo + j];
     #pragma unroll
-        for (int j = 0; j < PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
+        for (int j = 0; j < PF; j++) Gn[j] = row_load(plane + (size_t)Un[j] * xs + rowbase, zl);
+        auto scan = [&](auto safe) {
         for (int k0 = klo; k0 < khi; k0 += PF) {
             int Gc[PF], Uc[PF];
     #pragma unroll
@@ -672,15 +710,17 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restric
     #pragma unroll
             for (int j = 0; j < PF; j++) Un[j] = planelist[k0 + PF + j];
     #pragma unroll
-            for (int j = 0; j < PF; j++) Gn[j] = (plane + (size_t)Un[j] * xs)[rowoff];
+            for (int j = 0; j < PF; j++) Gn[j] = row_load(plane + (size_t)Un[j] * xs + rowbase, zl);
     #pragma unroll
             for (int j = 0; j < PF; j++)
-                if (k0 + j < khi) env_add(E, g, e, Uc[j], Gc[j], div);
+                if (k0 + j < khi) env_add<G, POOL, decltype(safe)::value>(E, g, e, Uc[j], Gc[j], div);
         }
+        };
+        if (!POOL && !report && khi - klo <= cap) scan(std::true_type{}); else scan(std::false_type{});
         env_finish(E, g, e, e.deepest + 1, report ? &counters[7] : nullptr);
     }
     __syncthreads();
-    env_write(E, g, G * RB, sq, xs, (unsigned)rowoff, div);
+    env_write(E, g, G * RB, sq + rowbase, xs, zl, div);
 }
 
 // ---- lookup (device function in icpx_edt_dev.h) ----
