@@ -134,8 +134,31 @@ struct BestK {              // the K nearest, ascending; unused slots hold (INFI
     }
 };
 
+// The query as the search sees it in single precision. With qf = (float)q and u = 2^-24 the float sum
+// s = dx^2 + dy^2 + dz^2 of float differences to a target point t satisfies |q - t| >= sqrt(s) (1 - 3.1 u) - e,
+// e = u (|qx| + |qy| + |qz|) (one rounding of q, one of each difference, three of the sum), so a point with
+// s > (sqrt(B) + e)^2 (1 + 2^-20) is strictly farther than squared distance B. 2 sqrt(B) <= B / c + c for any c > 0
+// (c: the cell size), which turns the right-hand side into B k1 + k2 with per-query constants and no square root.
+struct QueryF {
+    float x, y, z;
+    float k1, k2;       // a point with float squared distance above fma(B, k1, k2) cannot be as near as B
+    float margin;       // shrinks the boxes: the slop of the float cell assignment plus that of the float box bound
+    __device__ __forceinline__ QueryF(double qx, double qy, double qz, double h) {
+        x = (float)qx; y = (float)qy; z = (float)qz;
+        const double sum = fabs(qx) + fabs(qy) + fabs(qz), e = 0x1p-24 * sum;
+        k1 = (float)((1.0 + e / h) * (1.0 + 0x1p-19));
+        k2 = (float)((e * h + e * e) * (1.0 + 0x1p-19));
+        margin = (float)((1e-3 * h + 1.2e-6 * sum) * (1.0 + 0x1p-20));
+    }
+    __device__ __forceinline__ float point_threshold(double best) const { return fmaf((float)best, k1, k2); }
+};
+
+// What a float lower bound has to exceed to prove its box strictly farther than `best`: the bound below comes out at
+// most a factor 1 + 2^-20 above the exact one, the conversion at most 2^-24 below `best`.
+__device__ __forceinline__ float box_threshold(double best) { return (float)best * (1.f + 0x1p-19f); }
+
 template <class R>
-__device__ __forceinline__ void scan_cell(const GridView& g, int cell, double qx, double qy, double qz, R& b) {
+__device__ __forceinline__ void scan_cell(const GridView& g, int cell, double qx, double qy, double qz, const QueryF&, R& b) {
     const int first = g.start[cell], last = g.start[cell + 1];
     for (int k = first; k < last; k++) {
         const float4 p = g.pts[k];
@@ -145,18 +168,36 @@ __device__ __forceinline__ void scan_cell(const GridView& g, int cell, double qx
     }
 }
 
-// Distance from coordinate q to the interval [lo, hi], shrunk by `margin`, squared; 0 inside.
-__device__ __forceinline__ double axis_gap2(double q, double lo, double hi, double margin) {
-    double g = fmax(fmax(lo - q, q - hi) - margin, 0.0);
+// Single nearest: the points are compared in float first, the exact distance is formed only for those that the float
+// value cannot rule out.
+__device__ __forceinline__ void scan_cell(const GridView& g, int cell, double qx, double qy, double qz, const QueryF& f, Best& b) {
+    const int first = g.start[cell], last = g.start[cell + 1];
+    float thr = f.point_threshold(b.d2);
+    for (int k = first; k < last; k++) {
+        const float4 p = g.pts[k];
+        const float fx = f.x - p.x, fy = f.y - p.y, fz = f.z - p.z;
+        const float sf = (fx * fx + fy * fy) + fz * fz;
+        if (sf > thr) continue;
+        const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+        const double d = (dx * dx + dy * dy) + dz * dz;
+        b.offer(d, __float_as_int(p.w), k);
+        thr = f.point_threshold(b.d2);
+    }
+}
+
+// Distance from coordinate q to the interval [o + i side, o + (i + 1) side], shrunk by `margin`, squared; 0 inside.
+// In float: the ends carry one rounding each (2^-24 of their size), q one, the difference one; together less than
+// 2^-23 (|q| + gap), which the margin (absolute part) and box_threshold (relative part) allow for.
+__device__ __forceinline__ float axis_gap2(float q, float o, float side, int i, float margin) {
+    const float lo = fmaf((float)i, side, o), hi = fmaf((float)(i + 1), side, o);
+    const float g = fmaxf(fmaxf(lo - q, q - hi) - margin, 0.f);
     return g * g;
 }
 
 // Squared distance from q to the box of cell (i,j,k) at a level whose cells have side `side`, shrunk by
-// the margin so that it is a valid lower bound for every point filed under that cell.
-__device__ __forceinline__ double box_lb2(double qx, double qy, double qz, double ox, double oy, double oz, double side, int i, int j,
-                                          int k, double margin) {
-    return axis_gap2(qx, ox + i * side, ox + (i + 1) * side, margin) + axis_gap2(qy, oy + j * side, oy + (j + 1) * side, margin) +
-           axis_gap2(qz, oz + k * side, oz + (k + 1) * side, margin);
+// the margin so that (against box_threshold) it is a valid lower bound for every point filed under that cell.
+__device__ __forceinline__ float box_lb2(const QueryF& f, float ox, float oy, float oz, float side, int i, int j, int k) {
+    return (axis_gap2(f.x, ox, side, i, f.margin) + axis_gap2(f.y, oy, side, j, f.margin)) + axis_gap2(f.z, oz, side, k, f.margin);
 }
 
 // Children of a node in visiting order for a query whose nearest octant is `near`: bit t of the result is
@@ -247,7 +288,7 @@ constexpr int NN_STACK = 72;    // 1 + 7 entries for each of the (at most ten) l
 // the search from the start; the result does not depend on them (equal distances still go to the lower index
 // because cells are only skipped when their bound is strictly larger).
 template <class R>
-__device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsigned* snode, double* slb, const int oc, const int nocts,
+__device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsigned* snode, float* slb, const int oc, const int nocts,
                         const unsigned* loff, R b) {
     const int c = (int)(threadIdx.x & 7);
     const int cx = cell_coord((float)qx, g.minx, g.inv, g.dx), cy = cell_coord((float)qy, g.miny, g.inv, g.dy),
@@ -255,14 +296,18 @@ __device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsi
     const double h = (double)g.h;
     const double margin = 1e-3 * h + 1e-6 * (fabs(qx) + fabs(qy) + fabs(qz));
     const double ox = (double)g.minx, oy = (double)g.miny, oz = (double)g.minz;
+    const QueryF f(qx, qy, qz, h);
+    float bt = box_threshold(b.bound());
     // cells c, c + 8, c + 16, c + 24 of the 3x3x3 block
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int cc = c + 8 * r;
         const int i = cx + cc / 9 - 1, j = cy + (cc / 3) % 3 - 1, k = cz + cc % 3 - 1;
         if (cc < 27 && i >= 0 && i < g.dx && j >= 0 && j < g.dy && k >= 0 && k < g.dz &&
-            !(box_lb2(qx, qy, qz, ox, oy, oz, h, i, j, k, margin) > b.bound()))
-            scan_cell(g, (i * g.dy + j) * g.dz + k, qx, qy, qz, b);
+            !(box_lb2(f, g.minx, g.miny, g.minz, g.h, i, j, k) > bt)) {
+            scan_cell(g, (i * g.dy + j) * g.dz + k, qx, qy, qz, f, b);
+            bt = box_threshold(b.bound());
+        }
     }
     octet_merge(b);
     double outside = INFINITY;
@@ -284,29 +329,32 @@ __device__ R nn_search8(const GridView& g, double qx, double qy, double qz, unsi
     // Depth: one pop and at most eight pushes per level, NN_STACK covers the ten levels above the cells.
     int sp = 1;
     snode[oc] = (unsigned)top << 27;
-    slb[oc] = 0.0;
+    slb[oc] = 0.f;
+    bt = box_threshold(b.bound());
     while (sp > 0) {
         sp--;
         const unsigned node = snode[sp * nocts + oc];
-        if (slb[sp * nocts + oc] > b.bound()) continue;
+        if (slb[sp * nocts + oc] > bt) continue;
         const int l = (int)(node >> 27), ni = (int)((node >> 18) & 511), nj = (int)((node >> 9) & 511), nk = (int)(node & 511);
         const unsigned m = g.masks[loff[l] + ((size_t)ni * lev_dim(g.dy, l) + nj) * lev_dim(g.dz, l) + nk];
         const int cl = l - 1;
-        const double cside = h * (double)(1 << cl);
+        const float cside = g.h * (float)(1 << cl);   // exact: a power of two times h
         const int ci = 2 * ni + (c >> 2), cj = 2 * nj + ((c >> 1) & 1), ck = 2 * nk + (c & 1);
         const bool has = (m >> c) & 1u;
-        const double lb = has ? box_lb2(qx, qy, qz, ox, oy, oz, cside, ci, cj, ck, margin) : INFINITY;
-        const bool ok = has && !(lb > b.bound());
+        const float lb = has ? box_lb2(f, g.minx, g.miny, g.minz, cside, ci, cj, ck) : INFINITY;
+        const bool ok = has && !(lb > bt);
         if (cl == 0) {
             // the children are cells: every lane scans its own (those of the first block are done already)
             const bool seen = ci >= cx - 1 && ci <= cx + 1 && cj >= cy - 1 && cj <= cy + 1 && ck >= cz - 1 && ck <= cz + 1;
-            if (ok && !seen) scan_cell(g, (ci * g.dy + cj) * g.dz + ck, qx, qy, qz, b);
+            if (ok && !seen) scan_cell(g, (ci * g.dy + cj) * g.dz + ck, qx, qy, qz, f, b);
             octet_merge(b);
+            bt = box_threshold(b.bound());
             continue;
         }
         const unsigned cand = (unsigned)(__ballot(ok) >> (threadIdx.x & 56)) & 0xffu;
         if (cand == 0) continue;
-        const int near = (qx >= ox + (2 * ni + 1) * cside ? 4 : 0) | (qy >= oy + (2 * nj + 1) * cside ? 2 : 0) | (qz >= oz + (2 * nk + 1) * cside ? 1 : 0);
+        const int near = (f.x >= fmaf((float)(2 * ni + 1), cside, g.minx) ? 4 : 0) | (f.y >= fmaf((float)(2 * nj + 1), cside, g.miny) ? 2 : 0) |
+                         (f.z >= fmaf((float)(2 * nk + 1), cside, g.minz) ? 1 : 0);
         const unsigned vis = pyr_visit_order(cand, near);
         const int jc = c ^ near, t = jc == 3 ? 4 : jc == 4 ? 3 : jc;          // this lane's place in the visiting order
         const int n = __popc(cand);
@@ -349,7 +397,7 @@ template <int K>
 __global__ __launch_bounds__(256) void k_knn(GridView g, const double* __restrict__ q, size_t n, int kout, int* __restrict__ idx,
                                              double* __restrict__ d2) {
     __shared__ unsigned snode[NN_STACK * NN_OCTETS];
-    __shared__ double slb[NN_STACK * NN_OCTETS];
+    __shared__ float slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
@@ -370,7 +418,7 @@ __global__ __launch_bounds__(256) void k_knn(GridView g, const double* __restric
 
 __global__ __launch_bounds__(256) void k_nn(GridView g, const double* __restrict__ q, size_t n, int* __restrict__ idx, double* __restrict__ d2) {
     __shared__ unsigned snode[NN_STACK * NN_OCTETS];
-    __shared__ double slb[NN_STACK * NN_OCTETS];
+    __shared__ float slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
@@ -385,7 +433,7 @@ __global__ __launch_bounds__(256) void k_nn(GridView g, const double* __restrict
 
 __global__ __launch_bounds__(256) void k_nn_distance(GridView g, const float* __restrict__ q, size_t n, float* __restrict__ out) {
     __shared__ unsigned snode[NN_STACK * NN_OCTETS];
-    __shared__ double slb[NN_STACK * NN_OCTETS];
+    __shared__ float slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
@@ -702,7 +750,7 @@ __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __re
                                                   const unsigned* __restrict__ qcount, unsigned tiles_per_shard, int* __restrict__ idx_out,
                                                   int* __restrict__ seed) {
     __shared__ unsigned snode[NN_STACK * NN_OCTETS];
-    __shared__ double slb[NN_STACK * NN_OCTETS];
+    __shared__ float slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __shared__ unsigned s_count[WALK_SHARDS];
@@ -755,7 +803,7 @@ __global__ __launch_bounds__(256) void k_icp_pairs(GridView g, const float4* __r
                                                    unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
                                                    double* __restrict__ pbuf, int* __restrict__ idx, size_t nt, int* __restrict__ seed) {
     __shared__ unsigned snode[NN_STACK * NN_OCTETS];
-    __shared__ double slb[NN_STACK * NN_OCTETS];
+    __shared__ float slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
     if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
     __syncthreads();
