@@ -77,14 +77,16 @@ def _newest_profile(pattern):
 
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest rocprofv3 counter summary under profiles/
-    (FETCH_SIZE + WRITE_SIZE, KiB, collected in separate --pmc passes by tools/prof_round.sh); None when
-    no summary is present. Offline evidence, not measured by this run."""
+    (2 * FETCH_SIZE + WRITE_SIZE, KiB, collected in separate --pmc passes by tools/prof_round.sh); None when
+    no summary is present. Offline evidence, not measured by this run. On gfx950 FETCH_SIZE reports half of the
+    bytes read (128-byte requests tallied at 64), for 4-byte as for 16-byte loads per lane, and WRITE_SIZE the
+    bytes written exactly: tools/fetch_calib.hip streams a known 1 GiB in both widths and reads 0.500 / 1.000."""
     data = _newest_profile("r*_edt_pmc.json")
     if not data:
         return None
     for name, c in data.items():
         if isinstance(c, dict) and name.startswith(kernel) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
     return None
 
 
@@ -95,7 +97,7 @@ def measured_nn_traffic():
     if not data:
         return None
     try:
-        return sum((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 for c in data["converged_pass"].values())
+        return sum((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 for c in data["converged_pass"].values())   # see measured_traffic
     except Exception:
         return None
 

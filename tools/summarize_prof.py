@@ -33,7 +33,7 @@ for d in ("fetch", "write", "sq"):
         for c, v in agg[k].items():
             out.setdefault(k, {})[c] = sum(v) / len(v)
 out["_note"] = ("per-launch averages; FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them (separate --pmc passes). "
-                "The kernels issue 4-byte-per-lane loads, for which the gfx950 FETCH_SIZE scale is uncalibrated "
-                "(it reads 1/2 for 16-byte-per-lane streams); WRITE_SIZE matched the expected store bytes.")
+                "On gfx950 FETCH_SIZE is half of the bytes read, for 4-byte and 16-byte loads per lane alike, and WRITE_SIZE is "
+                "exact (tools/fetch_calib.hip: 0.500 / 1.000 of a streamed GiB); HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE.")
 json.dump(out, open(f"profiles/{tag}_edt_pmc.json", "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {c: v for c, v in d.items() if c in ("FETCH_SIZE", "WRITE_SIZE")} for k, d in out.items() if isinstance(d, dict)}, indent=1))
