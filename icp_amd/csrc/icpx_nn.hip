@@ -468,6 +468,13 @@ struct Mat34 { double m[12]; };
 constexpr int TILE_CAP = 512;            // points staged at a time: 8 KiB of LDS (a power of two: slots are packed into TILE_CAP - 1 bits)
 constexpr int TILE_COLS = 256;           // most columns of a box
 constexpr int TILE_MAX_PTS = 1536;       // most points of a box: a few times the usual number, so that no tile takes many times as long as the others
+constexpr int WALK_SHARDS = 64;          // parts of the walk queue and of the far-tile queue (one wave's lanes read the 64 counts)
+constexpr int BALL_MIN_LANES = 8;        // a tile with at least this many open points goes to k_icp_ball, fewer are walked one by one
+constexpr int BALL_MAX_COLS = 16384;     // most cell columns under a tile's ball; beyond that the points are left to the walk
+constexpr int BALL_MAX_PTS = 16384;      // most points staged for a tile: a tile whose queries lie far apart (the Morton order jumps) has a ball full
+                                         // of points, not a shell; its points are cheaper to walk one by one
+constexpr float BALL_MIN_REACH = 2.f;    // a query at least this many cells from its candidate counts as far from the surface
+constexpr float BALL_MAX_SPREAD = 12.f;  // most cells from the tile's centre to one of its queries, for the same reason
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -552,7 +559,7 @@ __device__ __forceinline__ size_t icp_tile_of(int tt, int tiles_per_wave) {
 // so waves that are resident together work on neighbouring tiles, whose cell columns overlap, out of one L2. One
 // counter takes about 88 additions per microsecond; an eighth of the tiles of a million points needs 2 000. seed (in / out): per source position, the position of its pair in the sorted target points.
 #ifdef ICPX_NN_STATS
-__device__ unsigned long long g_nn_stats[8];
+__device__ unsigned long long g_nn_stats[16];
 __device__ unsigned long long g_nn_t0[8192], g_nn_t1[8192];
 __device__ unsigned g_nn_tile_t[1 << 18], g_nn_tile_steps[1 << 18], g_nn_tile_total[1 << 18];
 #endif
@@ -560,7 +567,8 @@ __device__ unsigned g_nn_tile_t[1 << 18], g_nn_tile_steps[1 << 18], g_nn_tile_to
 __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
                                                               int* __restrict__ idx_out, int* __restrict__ seed, size_t tiles_per_group,
                                                               unsigned long long* __restrict__ counters, unsigned long long counter_base,
-                                                              unsigned* __restrict__ queue, unsigned* __restrict__ qcount, unsigned tiles_per_shard) {
+                                                              unsigned* __restrict__ queue, unsigned* __restrict__ qcount, unsigned tiles_per_shard,
+                                                              unsigned* __restrict__ far_queue, unsigned long long* __restrict__ far_mask) {
     __shared__ float4 sw_pts[TILE_WAVES][TILE_CAP + 8];         // as four arrays of TILE_CAP words: x, y, z, slot number
     __shared__ int sw_first[TILE_WAVES][TILE_COLS];       // per column of the box: start of its run in the sorted points
     __shared__ int sw_pre[TILE_WAVES][TILE_COLS + 4];     // ... and the number of box points in the columns before it
@@ -724,7 +732,17 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         if (lane == 0 && tile < (1u << 18)) { g_nn_tile_t[tile] = (unsigned)(wall_clock64() - tile_t0); g_nn_tile_steps[tile] = tile_steps; g_nn_tile_total[tile] = (unsigned)total; }
 #endif
         const unsigned long long pend = __ballot(valid && !settled);
-        if (pend) {
+        // open lanes without a candidate, or BALL_MIN_REACH cells and more from it (k_icp_ball's test for a far query)
+        const double reach2 = (double)BALL_MIN_REACH * h * (double)BALL_MIN_REACH * h;
+        const int far_lanes = __popcll(__ballot(valid && !settled && !(b.d2 < reach2)));
+        if (__popcll(pend) >= BALL_MIN_LANES && far_lanes >= 4) {
+            // many of the tile's points are open and several are far from the surface: the tile goes to k_icp_ball as a whole, with the lanes it has to settle
+            const size_t shard = tile / tiles_per_shard;
+            if (lane == 0) {
+                far_queue[shard * tiles_per_shard + atomicAdd(&qcount[shard * 16 + 1], 1u)] = (unsigned)tile;
+                far_mask[tile] = pend;
+            }
+        } else if (pend) {
             const size_t shard = tile / tiles_per_shard;
             unsigned at = 0;
             if (lane == 0) at = atomicAdd(&qcount[shard * 16], (unsigned)__popcll(pend));
@@ -740,12 +758,294 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
 #endif
 }
 
+// A real target point near q, found without backtracking: down the pyramid into the first occupied child in visiting
+// order, then the nearest point of the cell reached. Only an upper bound on the nearest distance is wanted.
+__device__ __forceinline__ void greedy_candidate(const GridView& g, const unsigned* __restrict__ loff, double qx, double qy, double qz, Best& b) {
+    int l = g.nlev - 1, ni = 0, nj = 0, nk = 0;
+    const float fx = (float)qx, fy = (float)qy, fz = (float)qz;
+    while (l > 0) {
+        const unsigned m = g.masks[loff[l] + ((size_t)ni * lev_dim(g.dy, l) + nj) * lev_dim(g.dz, l) + nk];
+        if (m == 0) return;
+        const float cside = g.h * (float)(1 << (l - 1));
+        const int near = (fx >= fmaf((float)(2 * ni + 1), cside, g.minx) ? 4 : 0) | (fy >= fmaf((float)(2 * nj + 1), cside, g.miny) ? 2 : 0) |
+                         (fz >= fmaf((float)(2 * nk + 1), cside, g.minz) ? 1 : 0);
+        const int t = __ffs(pyr_visit_order(m, near)) - 1;
+        const int c = near ^ (t == 3 ? 4 : t == 4 ? 3 : t);
+        ni = 2 * ni + (c >> 2); nj = 2 * nj + ((c >> 1) & 1); nk = 2 * nk + (c & 1);
+        l--;
+    }
+    const int cell = (ni * g.dy + nj) * g.dz + nk;
+    for (int k = g.start[cell]; k < g.start[cell + 1]; k++) {
+        const float4 p = g.pts[k];
+        const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+        b.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(p.w), k);
+    }
+}
+
+// Tiles that k_icp_tile could not settle (queries farther from the surface than its ring of cells, or a box too full):
+// one wave per tile again, but the candidates are the target points inside a ball. Every open lane holds a real target
+// point as candidate (its previous pair, what the box gave, or what a greedy descent finds; the lanes then try each
+// other's), at distance r from its query q, so its nearest point lies within r of q and within R = max (|q - c| + r)
+// of the centre c of the queries. The ball (c, R) is covered column by column (its chord through a column of cells is
+// one run of the sorted points; the columns that hold points are collected 256 at a time and their points staged in
+// LDS 512 at a time), every lane against every point in float, keeping the smallest and second smallest float distance
+// and the smallest one's place. The float distance is taken relative to the centre: with t' = fl(t - c), w = fl(|t'|^2)
+// (staged once per point) and q' = fl(q - c), the three multiply-adds s = w - 2 q'.t' differ from |q - t|^2 - |q - c|^2
+// by at most 8.1 u M, u = 2^-24, M = |t - c|^2 + 2 |q - c| |t - c| (one rounding per coordinate of t' and q', three in
+// w, three in s, each relative to a partial result of size at most M): the result has the size of its largest term,
+// nothing cancels. M is at most (R + 3.5 cells + spread)^2 for every staged point, so E = 10 u (...)^2 bounds the error
+// of every s of the tile. Nothing inside the ball is nearer to c than the nearest candidate minus the queries'
+// spread, so what is staged is a thin shell around the queries' nearest points: a few thousand points for a tile 30
+// cells from the surface, where the pyramid walk expands about a hundred nodes for every single query. The winner's
+// exact distance shows whether the runner-up could be as near (prune_threshold). Lanes for which it could, tiles with
+// fewer than four queries BALL_MIN_REACH cells or more from their candidates (walks from a near candidate are short),
+// and queries whose ball would be too wide or too full go to the walk queue. A tile whose queries lie far apart (the Morton order jumps) is cut into aligned runs of lanes, down to eight, until a run's queries lie together.
+// Work is handed out at run time, like the tiles of k_icp_tile: the list of far tiles (part by part) is cut into eight
+// runs, one per XCD, taken in order through the counters qcount[16 g + 2] (zero before the launch).
+__global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
+                                                              int* __restrict__ idx_out, int* __restrict__ seed, const unsigned* __restrict__ far_queue,
+                                                              const unsigned long long* __restrict__ far_mask, unsigned* __restrict__ queue,
+                                                              unsigned* __restrict__ qcount, unsigned tiles_per_shard) {
+    __shared__ float sw_xyz[TILE_WAVES][4][TILE_CAP + 8];
+    __shared__ int sw_first[TILE_WAVES][TILE_COLS];
+    __shared__ int sw_pre[TILE_WAVES][TILE_COLS + 4];
+    __shared__ unsigned s_loff[MAXLEV];
+    if (threadIdx.x < MAXLEV) s_loff[threadIdx.x] = g.loff[threadIdx.x];
+    __syncthreads();
+    float* const s_x = sw_xyz[threadIdx.x >> 6][0];
+    float* const s_y = sw_xyz[threadIdx.x >> 6][1];
+    float* const s_z = sw_xyz[threadIdx.x >> 6][2];
+    float* const s_w = sw_xyz[threadIdx.x >> 6][3];
+    int* const s_first = sw_first[threadIdx.x >> 6];
+    int* const s_pre = sw_pre[threadIdx.x >> 6];
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned my_count = qcount[lane * 16 + 1];            // lane r: far tiles of part r (WALK_SHARDS == 64)
+    const unsigned most = (unsigned)wave_max((int)my_count);
+    const unsigned items = most * WALK_SHARDS, group = blockIdx.x & 7u, per_group = (items + 7) / 8;
+    const float h = g.h, big = 3e38f;
+
+    for (;;) {
+        unsigned taken = 0;
+        if (lane == 0) taken = atomicAdd(&qcount[group * 16 + 2], 1u);
+        taken = __shfl(taken, 0);
+        const unsigned item = group * per_group + taken;
+        if (taken >= per_group || item >= items) break;       // uniform
+        const unsigned shard = item / most, e = item % most;
+        if (e >= (unsigned)__shfl((int)my_count, (int)shard)) continue;
+        const size_t tile = far_queue[(size_t)shard * tiles_per_shard + e], base = tile * 64;
+        const unsigned long long open = far_mask[tile];
+        const bool mine = (open >> lane) & 1ull;
+        const size_t i = base + lane < n ? base + lane : n - 1;
+        const float4 s = src[i];
+        double p[3];
+        icp_transform(T, s, p);
+        Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);
+        if (mine && b.pos < 0) greedy_candidate(g, s_loff, p[0], p[1], p[2], b);
+        // the lanes' queries are neighbours: try each other's candidates
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int other = __shfl_xor(b.pos, o);
+            if (mine && other >= 0 && other != b.pos) {
+                const float4 t = g.pts[other];
+                const double dx = p[0] - (double)t.x, dy = p[1] - (double)t.y, dz = p[2] - (double)t.z;
+                b.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(t.w), other);
+            }
+        }
+        const float qx = (float)p[0], qy = (float)p[1], qz = (float)p[2];
+        const double r_q = __dsqrt_rn(b.d2);                    // infinite without a candidate (empty target)
+        const bool want = mine && r_q < 1e30;
+        const bool far = want && r_q * (double)g.inv >= (double)BALL_MIN_REACH;
+        bool settled = false;
+        int staged_pts = 0;
+        // parts: aligned runs of lanes, the whole tile first; a part whose queries lie too far apart is cut in two
+        for (int off = 0, size = 64; off < 64;) {
+            const bool sel = want && lane >= off && lane < off + size;
+            const int here = off, width = size;
+            off += size;                                        // what comes next unless this part is cut
+            size = min(off & -off, 64);
+            // worth a ball only for several queries away from the surface (the near ones then come along for free); a walk from a
+            // near candidate is short, and eight lanes per query beat one wave per tile
+            if (__popcll(__ballot(sel && far)) < 4) {
+#ifdef ICPX_NN_STATS
+                { const unsigned long long k = __popcll(__ballot(sel)); if (lane == 0) atomicAdd(&g_nn_stats[8], k); }
+#endif
+                continue;
+            }
+            // the ball: centre of the selected queries' box, radius over the selected lanes
+            float lox = sel ? qx : big, hix = sel ? qx : -big, loy = sel ? qy : big, hiy = sel ? qy : -big, loz = sel ? qz : big, hiz = sel ? qz : -big;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lox = fminf(lox, __shfl_xor(lox, o)); hix = fmaxf(hix, __shfl_xor(hix, o));
+                loy = fminf(loy, __shfl_xor(loy, o)); hiy = fmaxf(hiy, __shfl_xor(hiy, o));
+                loz = fminf(loz, __shfl_xor(loz, o)); hiz = fmaxf(hiz, __shfl_xor(hiz, o));
+            }
+            const float cx = 0.5f * (lox + hix), cy = 0.5f * (loy + hiy), cz = 0.5f * (loz + hiz);
+            // the query relative to the centre, and its squared length
+            const double ex = p[0] - (double)cx, ey = p[1] - (double)cy, ez = p[2] - (double)cz, qb2 = (ex * ex + ey * ey) + ez * ez;
+            const double spread_d = sel ? __dsqrt_rn(qb2) : 0.0;
+            float R = sel ? (float)(spread_d + r_q) : 0.f, spread = (float)spread_d;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { R = fmaxf(R, __shfl_xor(R, o)); spread = fmaxf(spread, __shfl_xor(spread, o)); }
+            if (spread * g.inv > BALL_MAX_SPREAD) {
+#ifdef ICPX_NN_STATS
+                { const unsigned long long k = __popcll(__ballot(sel)); if (lane == 0 && width == 8) atomicAdd(&g_nn_stats[9], k); }
+#endif
+                if (width > 8) { off = here; size = width / 2; }
+                continue;
+            }
+            // a little more than the ball: covers the roundings here and points filed a hair outside their cell's box
+            const float Rw = R * (1.f + 1e-5f) + 0.02f * h, R2 = Rw * Rw;
+            const float reach_cells = Rw * g.inv;
+            if (!(reach_cells < 4096.f)) continue;
+            const int w = (int)reach_cells + 2;
+            const int ccx = (int)floorf((cx - g.minx) * g.inv), ccy = (int)floorf((cy - g.miny) * g.inv);
+            const int x0 = max(ccx - w, 0), x1 = min(ccx + w, g.dx - 1), y0 = max(ccy - w, 0), y1 = min(ccy + w, g.dy - 1);
+            const int nby = max(y1 - y0 + 1, 1);
+            const long long nc = (long long)max(x1 - x0 + 1, 0) * (long long)max(y1 - y0 + 1, 0);
+#ifdef ICPX_NN_STATS
+            { const unsigned long long k = __popcll(__ballot(sel)); if (lane == 0 && nc > BALL_MAX_COLS) atomicAdd(&g_nn_stats[10], k); }
+#endif
+            if (nc > BALL_MAX_COLS) continue;
+            const int ncols = (int)nc;
+
+            const float mx = -2.f * (float)ex, my = -2.f * (float)ey, mz = -2.f * (float)ez;
+            float u1 = INFINITY, u2 = INFINITY;
+            int best_at = -1, nfill = 0, total = 0;
+            bool covered = true;
+            wave_sync();                                        // whoever used the tables before is done with them
+            constexpr int AHEAD = 4;             // rounds of 64 columns whose cell_start reads are in flight together
+            int firsts[AHEAD], ends[AHEAD];
+            for (int c0 = 0; c0 < ncols; c0 += 64) {
+                // 64 columns: those that hold points inside the ball join the batch
+                const int slot = (c0 >> 6) % AHEAD;
+                if (slot == 0) {
+#pragma unroll
+                    for (int a = 0; a < AHEAD; a++) {
+                        const int c = c0 + 64 * a + lane;
+                        firsts[a] = 0; ends[a] = 0;
+                        if (c < ncols) {
+                            const int ci = x0 + c / nby, cj = y0 + c % nby;
+                            const float lx = fmaf((float)ci, h, g.minx), ly = fmaf((float)cj, h, g.miny);
+                            const float dx = fmaxf(fmaxf(lx - cx, cx - (lx + h)), 0.f), dy = fmaxf(fmaxf(ly - cy, cy - (ly + h)), 0.f);
+                            const float rest = R2 - (dx * dx + dy * dy);
+                            if (rest >= 0.f) {
+                                const float half = __fsqrt_rn(rest);
+                                const int k0 = max((int)floorf((cz - half - g.minz) * g.inv - 0.02f), 0);
+                                const int k1 = min((int)floorf((cz + half - g.minz) * g.inv + 0.02f), g.dz - 1);
+                                if (k0 <= k1) {
+                                    const size_t cbase = ((size_t)ci * g.dy + cj) * g.dz;
+                                    firsts[a] = g.start[cbase + k0];
+                                    ends[a] = g.start[cbase + k1 + 1];
+                                }
+                            }
+                        }
+                    }
+                }
+                int first = 0, cnt = 0;
+#pragma unroll
+                for (int a = 0; a < AHEAD; a++) if (slot == a) { first = firsts[a]; cnt = ends[a] - firsts[a]; }
+                const unsigned long long has = __ballot(cnt > 0);
+                if (has) {
+                    int pre = cnt;               // inclusive prefix sum over the lanes
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o); if (lane >= o) pre += v; }
+                    if (cnt > 0) {
+                        const int at = nfill + __popcll(has & ((1ull << lane) - 1ull));
+                        s_first[at] = first; s_pre[at] = total + pre - cnt;
+                    }
+                    nfill += __popcll(has);
+                    total += __shfl(pre, 63);
+                }
+                const bool last = c0 + 64 >= ncols;
+                if (nfill == 0 || (!last && nfill <= TILE_COLS - 64)) continue;
+                // the batch: nfill columns, total points
+                staged_pts += total;
+                if (staged_pts > BALL_MAX_PTS) { covered = false; break; }
+                if (lane == 0) s_pre[nfill] = total;
+                int i1 = -1;                     // list position of the smallest distance, if it is found in this batch
+                for (int lo = 0; lo < total; lo += TILE_CAP) {
+                    const int hi = min(lo + TILE_CAP, total), m = hi - lo;
+                    wave_sync();                 // column tables written / the previous part has been compared
+                    // a lane per list position: its column by bisection of the prefix sums, then all of the lane's reads at once
+                    // (column by column, as k_icp_tile copies its few dozen columns, the reads of the next column would wait for
+                    // the LDS writes of this one: a ball has hundreds of short columns)
+                    int src_at[TILE_CAP / 64];
+#pragma unroll
+                    for (int r = 0; r < TILE_CAP / 64; r++) {
+                        const int v = lo + 64 * r + lane;
+                        int cc = 0, top = nfill - 1;
+                        while (cc < top) { const int mid = (cc + top + 1) >> 1; if (s_pre[mid] <= v) cc = mid; else top = mid - 1; }
+                        src_at[r] = v < hi ? s_first[cc] + (v - s_pre[cc]) : -1;
+                    }
+                    float4 pt[TILE_CAP / 64];
+#pragma unroll
+                    for (int r = 0; r < TILE_CAP / 64; r++) pt[r] = src_at[r] >= 0 ? g.pts[src_at[r]] : make_float4(3e18f, 3e18f, 3e18f, 0.f);
+#pragma unroll
+                    for (int r = 0; r < TILE_CAP / 64; r++)
+                        if (src_at[r] >= 0) {        // the point relative to the centre, and its squared length
+                            const float tx = pt[r].x - cx, ty = pt[r].y - cy, tz = pt[r].z - cz;
+                            s_x[64 * r + lane] = tx; s_y[64 * r + lane] = ty; s_z[64 * r + lane] = tz;
+                            s_w[64 * r + lane] = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+                        }
+                    if (lane < ((4 - (m & 3)) & 3)) { s_x[m + lane] = 0.f; s_y[m + lane] = 0.f; s_z[m + lane] = 0.f; s_w[m + lane] = 3e37f; }   // fills the last group of four
+                    wave_sync();
+                    for (int k = 0; k < m; k += 4) {
+                        const float4 X = *reinterpret_cast<const float4*>(s_x + k), Y = *reinterpret_cast<const float4*>(s_y + k),
+                                     Z = *reinterpret_cast<const float4*>(s_z + k), W = *reinterpret_cast<const float4*>(s_w + k);
+                        const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w}, ws[4] = {W.x, W.y, W.z, W.w};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float sf = fmaf(mx, xs[j], fmaf(my, ys[j], fmaf(mz, zs[j], ws[j])));   // |t - q|^2 - |q|^2, both relative to the centre
+                            i1 = sf < u1 ? lo + k + j : i1;
+                            u2 = __builtin_amdgcn_fmed3f(u1, u2, sf);     // u1 <= u2: the second smallest of the three
+                            u1 = fminf(u1, sf);
+                        }
+                    }
+                }
+                if (i1 >= 0) {                   // the column of that list position: the last one that starts at or before it
+                    int cc = 0, hi = nfill - 1;
+                    while (cc < hi) { const int mid = (cc + hi + 1) >> 1; if (s_pre[mid] <= i1) cc = mid; else hi = mid - 1; }
+                    best_at = s_first[cc] + (i1 - s_pre[cc]);
+                }
+                nfill = 0; total = 0;
+                wave_sync();                     // the tables are free again
+            }
+#ifdef ICPX_NN_STATS
+            { const unsigned long long k = __popcll(__ballot(sel)); if (lane == 0 && !covered) atomicAdd(&g_nn_stats[11], k); }
+#endif
+            if (sel && covered && best_at >= 0) {
+                const float4 t = g.pts[best_at];
+                const double ex = p[0] - (double)t.x, ey = p[1] - (double)t.y, ez = p[2] - (double)t.z;
+                const double d = (ex * ex + ey * ey) + ez * ez;
+                // every other staged point B has |q - B|^2 >= u2 + |q - c|^2 - E (see above): strictly farther when that exceeds d
+                const double far_most = (double)Rw + 3.5 * (double)h + (double)spread * (1.0 + 1e-5), E = 10.0 * 0x1p-24 * far_most * far_most;
+                settled = (double)u2 > (d - qb2) + E;
+                b.offer(d, __float_as_int(t.w), best_at);
+            }
+        }
+        const unsigned long long pend = __ballot(mine && !settled);
+#ifdef ICPX_NN_STATS
+        const unsigned long long k_near = __popcll(__ballot(mine && !want));
+        if (lane == 0) { atomicAdd(&g_nn_stats[2], 1ull); atomicAdd(&g_nn_stats[3], __popcll(pend) < __popcll(open) ? 1ull : 0ull); atomicAdd(&g_nn_stats[4], (unsigned long long)staged_pts);
+                         atomicAdd(&g_nn_stats[5], (unsigned long long)__popcll(pend)); atomicAdd(&g_nn_stats[12], k_near); }
+#endif
+        if (pend) {
+            unsigned at = 0;
+            if (lane == 0) at = atomicAdd(&qcount[shard * 16], (unsigned)__popcll(pend));
+            at = __shfl(at, 0);
+            if ((pend >> lane) & 1ull) queue[(size_t)shard * tiles_per_shard * 64 + at + __popcll(pend & ((1ull << lane) - 1ull))] = (unsigned)i;
+        }
+        if (!mine) continue;
+        seed[i] = b.pos;
+        if (settled && idx_out) idx_out[__float_as_int(s.w)] = b.idx;
+    }
+}
+
 // The queued source points: eight lanes each, the pyramid walk of nn_search8 from the candidate in seed[]. The work is
 // cut into groups of NN_OCTETS consecutive entries of one part of the queue (see k_icp_tile), numbered part by part,
 // and dealt to the workgroups in turn: the workgroups that are resident together work on one stretch of the cloud
 // (whose cells and pyramid nodes then stay in L2: spreading them over the whole cloud cost a third more time), and
 // over its life every workgroup gets groups from all over the cloud (how long a walk takes depends on where the query is).
-constexpr int WALK_SHARDS = 64;
 __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __restrict__ src, Mat34 T, size_t nt, const unsigned* __restrict__ queue,
                                                   const unsigned* __restrict__ qcount, unsigned tiles_per_shard, int* __restrict__ idx_out,
                                                   int* __restrict__ seed) {
@@ -758,6 +1058,9 @@ __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __re
     __syncthreads();
     unsigned most = 0;
     for (int r = 0; r < WALK_SHARDS; r++) most = max(most, s_count[r]);
+#ifdef ICPX_NN_STATS
+    if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long w = 0; for (int r = 0; r < WALK_SHARDS; r++) w += s_count[r]; atomicAdd(&g_nn_stats[13], w); }
+#endif
     const size_t per_part = (most + NN_OCTETS - 1) / NN_OCTETS, items = per_part * WALK_SHARDS;
     for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
         const unsigned shard = (unsigned)(item / per_part), e = (unsigned)(item % per_part) * NN_OCTETS + (threadIdx.x >> 3);
@@ -863,13 +1166,15 @@ __global__ __launch_bounds__(256) void k_icp_trim_sums(const unsigned* __restric
         partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
-// clear16: nclear words, 16 words apart, set to zero on the way (nullptr: none).
+// clear16: nclear triples of words, 16 words apart, set to zero on the way (nullptr: none).
 // Fixed-order final reduction of the block partials (component-major: partials[component * nblocks + block]): one
 // workgroup per component, thread t adds blocks t, t + 256, ... in that order, then a tree over the threads.
 __global__ __launch_bounds__(256) void k_reduce_sums(const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
                                                      unsigned* __restrict__ clear16 = nullptr, int nclear = 0) {
     __shared__ double sm[256];
-    if (clear16 && blockIdx.x == 0 && (int)threadIdx.x < nclear) clear16[threadIdx.x * 16] = 0u;   // the walk queue's counters, for the next pass
+    if (clear16 && blockIdx.x == 0 && (int)threadIdx.x < nclear) {   // the queues' counters and the hand-out counters of k_icp_ball, for the next pass
+        clear16[threadIdx.x * 16] = 0u; clear16[threadIdx.x * 16 + 1] = 0u; clear16[threadIdx.x * 16 + 2] = 0u;
+    }
     const double* row = partials + (size_t)blockIdx.x * nblocks;
     double v = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) v += row[b];
@@ -1113,13 +1418,18 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
         ctx->tile_counter_base = 0;
     }
     const unsigned tiles_per_shard = (unsigned)((tiles + WALK_SHARDS - 1) / WALK_SHARDS);
-    const size_t queue_words = (size_t)WALK_SHARDS * 16 + (size_t)WALK_SHARDS * tiles_per_shard * 64;
+    // counters (per part: walk entries, far tiles), the walk queue, the far-tile queue, the far tiles' open lanes
+    const size_t far_off = (size_t)WALK_SHARDS * 16 + (size_t)WALK_SHARDS * tiles_per_shard * 64;
+    const size_t mask_off = (far_off + (size_t)WALK_SHARDS * tiles_per_shard + 1) / 2 * 2;
+    const size_t queue_words = mask_off + 2 * (size_t)WALK_SHARDS * tiles_per_shard;
     if (ctx->walk_queue.cap < queue_words * sizeof(unsigned)) {
         ICPX_TRY(icpx_reserve(ctx, ctx->walk_queue, queue_words * sizeof(unsigned)));
         ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->walk_queue.p, 0, WALK_SHARDS * 16 * sizeof(unsigned), ctx->stream));   // later passes: k_reduce_sums
     }
     unsigned* qcount = ctx->walk_queue.as<unsigned>();
     unsigned* queue = qcount + WALK_SHARDS * 16;
+    unsigned* far_queue = qcount + far_off;
+    unsigned long long* far_mask = reinterpret_cast<unsigned long long*>(qcount + mask_off);
     // every wave of a group adds once more than it gets tiles, and the group's tiles are added for once each
     const unsigned long long counter_base = ctx->tile_counter_base;
     ctx->tile_counter_base += tiles_per_group + (unsigned long long)(blocks / 8) * TILE_WAVES;
@@ -1128,7 +1438,10 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     const GridView g = view_of(ctx);
     double* part = ctx->partials.as<double>();
     hipLaunchKernelGGL(k_icp_tile, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
-                       ctx->nn_seed.as<int>(), tiles_per_group, ctx->tile_counters.as<unsigned long long>(), counter_base, queue, qcount, tiles_per_shard);
+                       ctx->nn_seed.as<int>(), tiles_per_group, ctx->tile_counters.as<unsigned long long>(), counter_base, queue, qcount, tiles_per_shard,
+                       far_queue, far_mask);
+    hipLaunchKernelGGL(k_icp_ball, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
+                       ctx->nn_seed.as<int>(), far_queue, far_mask, queue, qcount, tiles_per_shard);
     const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, (size_t)ctx->num_cus * 8 / WALK_SHARDS) * WALK_SHARDS);
     hipLaunchKernelGGL(k_icp_walk, dim3(std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
                        queue, qcount, tiles_per_shard, idx_dev, ctx->nn_seed.as<int>());
@@ -1137,11 +1450,14 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     hipLaunchKernelGGL(k_reduce_sums, dim3(ICPX_NSUMS), dim3(256), 0, ctx->stream, part, swaves, sums_dev, qcount, WALK_SHARDS);
 #ifdef ICPX_NN_STATS
     {
-        unsigned long long h[8];
+        unsigned long long h[16];
         hipStreamSynchronize(ctx->stream);
         hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nn_stats), sizeof h);
-        fprintf(stderr, "tiles %llu staged %llu cols/tile %.1f pts/staged tile %.1f\n", h[0], h[1], (double)h[6] / h[0], (double)h[7] / (h[1] ? h[1] : 1));
-        unsigned long long z[8] = {0};
+        fprintf(stderr, "tiles %llu staged %llu cols/tile %.1f pts/staged tile %.1f; far tiles %llu covered %llu pts/covered %.0f lanes left to the walk %llu\n", h[0], h[1], (double)h[6] / h[0], (double)h[7] / (h[1] ? h[1] : 1),
+                h[2], h[3], (double)h[4] / (h[3] ? h[3] : 1), h[5]);
+        fprintf(stderr, "   BALL left: near %llu, part<8 %llu, spread %llu, columns %llu, points %llu\n", h[12], h[8], h[9], h[10], h[11]);
+        fprintf(stderr, "   WALKQ %llu\n", h[13]);
+        unsigned long long z[16] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof z);
         static std::vector<unsigned long long> t0(8192), t1(8192);
         hipMemcpyFromSymbol(t0.data(), HIP_SYMBOL(g_nn_t0), 8192 * 8);
