@@ -119,3 +119,32 @@ def test_icp_step_million_by_million(oracle):
         assert np.array_equal(a, b)
     finally:
         ctx.close()
+
+
+def test_icp_step_far_from_the_surface_all_pairs(oracle):
+    """Queries many cells from the target (where the pass settles whole tiles against the shell of target points inside a
+    ball around them), every pair against brute force: first without previous pairs, then from pairs that belong to
+    another pose, then near alignment. The target holds 3 000 points twice, so equal distances occur and must go to
+    the lower index."""
+    from conftest import synth_surface
+    from icp_amd.api import Context
+    n = 40_000
+    base = synth_surface(n, 7)
+    tgt = np.ascontiguousarray(np.concatenate([base, base[5000:8000]]))
+    src = synth_surface(n, 8, noise=1e-3)
+    ctx = Context(0)
+    try:
+        ctx.set_target(tgt)
+        ctx.set_source(src)
+        poses = (rigid([1, 0.3, -0.2], 25.0, [0.15, -0.1, 0.05]), rigid([0, 1, 0.5], -15.0, [-0.05, 0.2, 0.1]),
+                 rigid([1, 1, 1], 2.0, [0.004, -0.002, 0.003]), np.eye(4))
+        for T in poses:
+            sums, idx = ctx.icp_step(T, want_idx=True)
+            p = _transform(src, T)
+            ridx, rd2 = oracle.nn_brute(np.ascontiguousarray(p), tgt)
+            assert np.array_equal(idx, ridx)
+            q = tgt[idx].astype(np.float64)
+            want = np.concatenate([p.sum(0), q.sum(0), (p.T @ q).reshape(9), [rd2.sum()]])
+            np.testing.assert_allclose(sums, want, rtol=1e-12, atol=1e-12)
+    finally:
+        ctx.close()
