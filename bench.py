@@ -259,7 +259,7 @@ def main():
             T = icp_iter(T, n, ctx2)
         conv_ms = float(np.mean(pass_ms[-10:]))
         alg = 36.0 * (hi - lo) + 12.0 * n      # this rank's queries + the whole target, bytes per pass
-        roofline_nn = {"bound": "hbm", "kernel": "k_icp_tile + k_icp_walk + k_icp_sums + k_reduce_sums (one ICP pass, this rank's share)",
+        roofline_nn = {"bound": "hbm", "kernel": "k_icp_tile + k_icp_ball + k_icp_walk + k_icp_sums + k_reduce_sums (one ICP pass, this rank's share)",
                        "algorithmic_bytes_per_pass": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "first_pass": {"ms": pass_ms[0], "achieved": alg / (pass_ms[0] * 1e-3) / 1e9,
                                       "frac": alg / (pass_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -77,6 +77,14 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
             g * 384 + 768 + g * (c + 1) * 384 + n * 48 <= 65536)
             { (k ? ctx->edt_x : ctx->edt_zy) = EnvTune{g, c, n}; ctx->edt_tune_fixed = true; }
     }
+    // ICPX_ICP_TILES = "walk_all,ball_min": source clouds with fewer 64-point tiles than walk_all are walked point by point
+    // without the tile kernel, clouds with at least ball_min tiles also use the ball kernel (defaults in icpx_ctx.h; the
+    // tests set 0,0 to run small clouds through every kernel)
+    {
+        const char* v = getenv("ICPX_ICP_TILES");
+        long long a = 0, b2 = 0;
+        if (v && sscanf(v, "%lld,%lld", &a, &b2) == 2 && a >= 0 && b2 >= 0) { ctx->icp_walk_all_tiles = (size_t)a; ctx->icp_ball_min_tiles = (size_t)b2; }
+    }
     if (icpx_bnb_scratch_init(ctx) != ICPX_OK) {
         g_create_error = "icpx_create: " + ctx->err;
         (void)hipStreamDestroy(ctx->own_stream);

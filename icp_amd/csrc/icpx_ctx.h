@@ -52,6 +52,8 @@ struct icpx_ctx {
     DevBuf nn_seed;          // ns int, by sorted source position: position in sorted_pts of the target point the source point was paired with by the last ICP pass, -1 = none
     DevBuf tile_counters;    // eight 64-bit counters, 64 B apart, that hand out the tiles of an ICP pass; never reset
     unsigned long long tile_counter_base = 0;   // their common value before the next launch
+    size_t icp_walk_all_tiles = 1024;           // source clouds with fewer tiles skip the tile kernel: every point is walked (ICPX_ICP_TILES)
+    size_t icp_ball_min_tiles = 2048;           // source clouds with at least this many tiles use the ball kernel for far tiles
     DevBuf walk_queue;       // one ICP pass: the source points left to the pyramid walk, in 64 parts: a counter per part (16 words apart, zero between passes), then the parts' entries
     DevBuf partials;         // per-block partial sums
     DevBuf sums;             // ICPX_NSUMS doubles

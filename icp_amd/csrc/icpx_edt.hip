@@ -211,9 +211,9 @@ struct Env {
     u64* ovf;                // overflow counter word
 
     // LDS header: depths [G][64] u16, chunk tables [G][64] u32, pool counter.
-    // Without the pool every stack has one more row below its level 0: a sentinel entry {site 0, a 0,
-    // start 0} that no site can pop, so the scan needs no "stack empty" test.
-    static constexpr int FIRST = POOL ? 0 : 1;
+    // Every stack has one more row below its level 0: a sentinel entry {site 0, the largest a, start 0}, which is
+    // what the hand-written site step sees as the top of an empty stack.
+    static constexpr int FIRST = 1;
     __device__ __forceinline__ int rows() const { return cap + FIRST; }
     __device__ __forceinline__ unsigned short& depth(int g) const { return *reinterpret_cast<unsigned short*>(lds + (g * 64 + lane) * 2); }
     __device__ __forceinline__ unsigned& table(int g) const { return *reinterpret_cast<unsigned*>(lds + G * 128 + (g * 64 + lane) * 4); }
@@ -289,11 +289,11 @@ __device__ __forceinline__ unsigned lds_address(const void* p) {
 
 template <int G, bool POOL>
 __device__ __forceinline__ void env_init(const Env<G, POOL>& E, int g, EnvTop& e) {
-    // Without the pool a sentinel entry sits below level 0 and is what an empty stack holds as its top: site 0 with
-    // the largest value there is, from position 0.
-    e = EnvTop{-1, POOL ? 0u : ENV_VMASK, 0, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu, -1, 0u, 0u};
+    // A sentinel entry sits below level 0 and is what an empty stack holds as its top: site 0 with the largest value
+    // there is, from position 0.
+    e = EnvTop{-1, ENV_VMASK, 0, 0u, 0, E.wbase(g), E.tbase(g), 0xffffffffu, -1, 0u, 0u};
     e.aw = lds_address(E.lds + e.wb - 256); e.at = lds_address(E.lds + e.tb - 128);
-    if (!POOL) { E.W(e.wb, -1) = ENV_VMASK; E.T(e.tb, -1) = 0; }
+    E.W(e.wb, -1) = ENV_VMASK; E.T(e.tb, -1) = 0;
 }
 
 // Adds site u (ascending) with value v to the stack of group g: pop while the new parabola is lower at
@@ -308,7 +308,9 @@ template <int G, bool POOL, bool SAFE = false>
 __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e, int u, int v, int div) {
     const int au = (u & 0x3ff) * (u & 0x3ff) + v;
     int d, dd, w;
-    if constexpr (!POOL) {
+    // With the pool the hand-written step serves as long as every stack of the wave stays below its last private level
+    // (it reads and writes private levels only); a wave with a deeper stack takes the general step for that site.
+    if (!POOL || __all(e.q < E.cap - 1)) {
         // The pop loop and the crossing, by hand. The loop runs while any lane of the wave has to pop and is
         // predicated instead of divergent (lanes that are done re-read the entry they already hold): 18
         // instructions per round where the compiled divergent loop needs about 30, most of them mask
@@ -383,7 +385,8 @@ __device__ __forceinline__ void env_add(const Env<G, POOL>& E, int g, EnvTop& e,
             : [u] "s"(u), [au] "v"(au), [aw] "v"(e.aw), [at] "v"(e.at), [div] "s"(div), [capm1] "s"(E.cap - 1), [safe] "n"(SAFE ? 1 : 0)
             : "vcc", "memory");
         return;
-    } else {
+    }
+    if constexpr (POOL) {
         for (;;) {
             d = u - (int)(e.tw >> ENV_VB); dd = (int)(e.tw & ENV_VMASK) - au;
             if (!(e.q >= 0 && __mul24(e.tt2, d) + dd > 0)) break;
@@ -568,7 +571,7 @@ __host__ __device__ inline int env_off_w(int G, int parts, bool pool) {
     const int pad = (64 + parts * 64 + 255) & ~255;
     return G * 384 + (pad < 512 ? 512 : pad);
 }
-static size_t env_lds_bytes(int G, int parts, int cap, int nch, bool pool) { return (size_t)env_off_w(G, parts, pool) + (size_t)G * (cap + (pool ? 0 : 1)) * 384 + (size_t)nch * ENV_CHUNK * 6; }
+static size_t env_lds_bytes(int G, int parts, int cap, int nch, bool pool) { return (size_t)env_off_w(G, parts, pool) + (size_t)G * (cap + 1) * 384 + (size_t)nch * ENV_CHUNK * 6; }
 
 template <int G, bool POOL>
 __device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int parts, int cap, int nch, int lane, uint2* sp, int div, size_t rows, size_t row,

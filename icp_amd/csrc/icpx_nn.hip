@@ -735,7 +735,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         // open lanes without a candidate, or BALL_MIN_REACH cells and more from it (k_icp_ball's test for a far query)
         const double reach2 = (double)BALL_MIN_REACH * h * (double)BALL_MIN_REACH * h;
         const int far_lanes = __popcll(__ballot(valid && !settled && !(b.d2 < reach2)));
-        if (__popcll(pend) >= BALL_MIN_LANES && far_lanes >= 4) {
+        if (far_queue && __popcll(pend) >= BALL_MIN_LANES && far_lanes >= 4) {
             // many of the tile's points are open and several are far from the surface: the tile goes to k_icp_ball as a whole, with the lanes it has to settle
             const size_t shard = tile / tiles_per_shard;
             if (lane == 0) {
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
 // over its life every workgroup gets groups from all over the cloud (how long a walk takes depends on where the query is).
 __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __restrict__ src, Mat34 T, size_t nt, const unsigned* __restrict__ queue,
                                                   const unsigned* __restrict__ qcount, unsigned tiles_per_shard, int* __restrict__ idx_out,
-                                                  int* __restrict__ seed) {
+                                                  int* __restrict__ seed, size_t n_all) {
     __shared__ unsigned snode[NN_STACK * NN_OCTETS];
     __shared__ float slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
@@ -1056,6 +1056,19 @@ __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __re
     __shared__ unsigned s_count[WALK_SHARDS];
     if (threadIdx.x < WALK_SHARDS) s_count[threadIdx.x] = qcount[threadIdx.x * 16];
     __syncthreads();
+    if (n_all) {
+        // no queue: every source point is walked (small clouds, see icp_step_enqueue)
+        for (size_t i = (size_t)blockIdx.x * NN_OCTETS + (threadIdx.x >> 3); i < n_all; i += (size_t)gridDim.x * NN_OCTETS) {
+            const float4 s = src[i];
+            double p[3];
+            icp_transform(T, s, p);
+            const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(g, seed, i, nt, p[0], p[1], p[2]));
+            if ((threadIdx.x & 7) != 0) continue;
+            seed[i] = b.pos;
+            if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
+        }
+        return;
+    }
     unsigned most = 0;
     for (int r = 0; r < WALK_SHARDS; r++) most = max(most, s_count[r]);
 #ifdef ICPX_NN_STATS
@@ -1428,7 +1441,11 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     }
     unsigned* qcount = ctx->walk_queue.as<unsigned>();
     unsigned* queue = qcount + WALK_SHARDS * 16;
-    unsigned* far_queue = qcount + far_off;
+    // k_icp_ball runs one wave per tile, one tile after the other: with few tiles (a scan of some ten thousand points) that is
+    // a handful of long serial jobs, and eight lanes per query in k_icp_walk, spread over the whole GPU, finish sooner
+    // (bunny pair, 626 tiles, 30 passes: 12.9 ms with the ball kernel, 5 ms without)
+    const bool use_ball = tiles >= ctx->icp_ball_min_tiles;
+    unsigned* far_queue = use_ball ? qcount + far_off : nullptr;
     unsigned long long* far_mask = reinterpret_cast<unsigned long long*>(qcount + mask_off);
     // every wave of a group adds once more than it gets tiles, and the group's tiles are added for once each
     const unsigned long long counter_base = ctx->tile_counter_base;
@@ -1437,14 +1454,21 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     for (int k = 0; k < 12; k++) M.m[k] = T[k];
     const GridView g = view_of(ctx);
     double* part = ctx->partials.as<double>();
+    // A small source cloud (a scan of some ten thousand points) is walked as a whole, eight lanes per point from its previous
+    // pair: its few hundred tiles would be a short kernel of long serial jobs followed by a second one for the leftovers
+    // (bunny pair, converged pass: 102 us as tile + walk, 65 us walked)
+    const bool walk_all = tiles < ctx->icp_walk_all_tiles;
+    if (!walk_all)
     hipLaunchKernelGGL(k_icp_tile, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
                        ctx->nn_seed.as<int>(), tiles_per_group, ctx->tile_counters.as<unsigned long long>(), counter_base, queue, qcount, tiles_per_shard,
                        far_queue, far_mask);
-    hipLaunchKernelGGL(k_icp_ball, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
-                       ctx->nn_seed.as<int>(), far_queue, far_mask, queue, qcount, tiles_per_shard);
+    if (use_ball)
+        hipLaunchKernelGGL(k_icp_ball, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
+                           ctx->nn_seed.as<int>(), far_queue, far_mask, queue, qcount, tiles_per_shard);
     const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, (size_t)ctx->num_cus * 8 / WALK_SHARDS) * WALK_SHARDS);
-    hipLaunchKernelGGL(k_icp_walk, dim3(std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
-                       queue, qcount, tiles_per_shard, idx_dev, ctx->nn_seed.as<int>());
+    const unsigned all_blocks = (unsigned)std::min<size_t>((ctx->ns + NN_OCTETS - 1) / NN_OCTETS, (size_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(k_icp_walk, dim3(walk_all ? all_blocks : std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
+                       queue, qcount, tiles_per_shard, idx_dev, ctx->nn_seed.as<int>(), walk_all ? ctx->ns : (size_t)0);
     hipLaunchKernelGGL(k_icp_sums, dim3(sblocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt,
                        ctx->nn_seed.as<int>(), tiles_per_sblock, part);
     hipLaunchKernelGGL(k_reduce_sums, dim3(ICPX_NSUMS), dim3(256), 0, ctx->stream, part, swaves, sums_dev, qcount, WALK_SHARDS);

@@ -121,17 +121,24 @@ def test_icp_step_million_by_million(oracle):
         ctx.close()
 
 
-def test_icp_step_far_from_the_surface_all_pairs(oracle):
+# ICPX_ICP_TILES (read when a context is created): which kernels a pass uses, by the number of 64-point tiles of the source
+PATHS = {"tile + ball + walk": "0,0", "tile + walk": "0,1000000000", "walk only": "1000000000,1000000000"}
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+def test_icp_step_far_from_the_surface_all_pairs(oracle, monkeypatch, path):
     """Queries many cells from the target (where the pass settles whole tiles against the shell of target points inside a
     ball around them), every pair against brute force: first without previous pairs, then from pairs that belong to
     another pose, then near alignment. The target holds 3 000 points twice, so equal distances occur and must go to
-    the lower index."""
+    the lower index. Once through each combination of kernels a pass can use (by default the size of the source
+    cloud decides)."""
     from conftest import synth_surface
     from icp_amd.api import Context
     n = 40_000
     base = synth_surface(n, 7)
     tgt = np.ascontiguousarray(np.concatenate([base, base[5000:8000]]))
     src = synth_surface(n, 8, noise=1e-3)
+    monkeypatch.setenv("ICPX_ICP_TILES", PATHS[path])
     ctx = Context(0)
     try:
         ctx.set_target(tgt)
@@ -146,5 +153,25 @@ def test_icp_step_far_from_the_surface_all_pairs(oracle):
             q = tgt[idx].astype(np.float64)
             want = np.concatenate([p.sum(0), q.sum(0), (p.T @ q).reshape(9), [rd2.sum()]])
             np.testing.assert_allclose(sums, want, rtol=1e-12, atol=1e-12)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+def test_icp_step_bunny_pair_every_path(oracle, bunny000, bunny045, monkeypatch, path):
+    """The scan pair (partial overlap: many source points have no near counterpart) through each combination of kernels:
+    same pairs, and the same bits in the 16 sums (their order of addition does not depend on which kernel settled a point)."""
+    from icp_amd.api import Context
+    monkeypatch.setenv("ICPX_ICP_TILES", PATHS[path])
+    ctx = Context(0)
+    try:
+        ctx.set_target(bunny045)
+        ctx.set_source(bunny000)
+        T = rigid([0.2, -1, 0.4], 8.0, [0.003, 0.001, -0.002])
+        for M in (np.eye(4), T, T):
+            sums, idx = ctx.icp_step(M, want_idx=True)
+            ref, ridx = _sums_ref(oracle, bunny000, bunny045, M)
+            assert np.array_equal(idx, ridx)
+            np.testing.assert_allclose(sums, ref, rtol=1e-12, atol=1e-12)
     finally:
         ctx.close()
