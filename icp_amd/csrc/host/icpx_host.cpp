@@ -186,6 +186,120 @@ float KDTree::Distance(float x0, float x1, float x2) {
     return out;
 }
 
+// ---- the icp/ fork's loop -----------------------------------------------------------------------------------
+
+namespace {
+struct KNeighbor {          // icp/src/icp.hpp:50-55, with the K target indices inline
+    int sourceIndex;
+    int targetIndexes[8];
+    float distanceMean;
+};
+
+// cmpKNeighbor (icp/src/icp.hpp:66-71) returns the float difference truncated to int; "a before b" when that is negative
+inline bool fork_before(const KNeighbor& a, const KNeighbor& b) {
+    const float d = a.distanceMean - b.distanceMean;
+    return d <= -1.0f;      // (int)d < 0, without the undefined conversion of a huge difference
+}
+
+// Stable bottom-up merge sort under that comparator (runs of 1, 2, 4, ...; the left run wins unless the right element is
+// strictly before it). The comparator is not a strict weak order, so the result is defined by this procedure, not by
+// "sortedness"; the CPU restatement in oracle/ follows the same procedure.
+void fork_order(std::vector<KNeighbor>& v) {
+    const size_t n = v.size();
+    std::vector<KNeighbor> tmp(n);
+    for (size_t w = 1; w < n; w *= 2) {
+        for (size_t lo = 0; lo < n; lo += 2 * w) {
+            const size_t mid = std::min(lo + w, n), hi = std::min(lo + 2 * w, n);
+            size_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) tmp[k++] = fork_before(v[j], v[i]) ? v[j++] : v[i++];
+            while (i < mid) tmp[k++] = v[i++];
+            while (j < hi) tmp[k++] = v[j++];
+        }
+        v.swap(tmp);
+    }
+}
+}  // namespace
+
+ICP_OUT knn_icp(const PointCloudTPtr& A, const PointCloudTPtr& B, int max_iteration, float tolerance, int K, int remainPercentage, DevicePtr dev) {
+    if (!A || !B || A->points.empty() || B->points.empty()) throw IcpxFailure(ICPX_EINVAL, "knn_icp: empty cloud");
+    if (K < 1 || K > 8) throw IcpxFailure(ICPX_EINVAL, "knn_icp: K must be in [1, 8]");
+    if (remainPercentage < 0 || remainPercentage > 100) throw IcpxFailure(ICPX_EINVAL, "knn_icp: remainPercentage must be in [0, 100]");
+    const size_t na = A->points.size(), nb = B->points.size();
+    if (nb > na) throw IcpxFailure(ICPX_EINVAL, "knn_icp: the target cloud must not be larger than the source cloud (the fork reads beyond its matrix then)");
+    if (nb < (size_t)K) throw IcpxFailure(ICPX_EINVAL, "knn_icp: fewer target points than K");
+    const size_t row = nb;                                       // min(A.rows(), B.rows()), icp.hpp:401
+    KDTree kd(B, 3, dev);
+    std::vector<double> src(3 * row), q(3 * row), d2(row * (size_t)K);
+    std::vector<int32_t> idx(row * (size_t)K);
+    for (size_t i = 0; i < row; i++) { src[3 * i] = A->points[i].x; src[3 * i + 1] = A->points[i].y; src[3 * i + 2] = A->points[i].z; }
+    auto Bp = [&](int j, int c) { const Point3f& p = B->points[j]; return (double)(c == 0 ? p.x : c == 1 ? p.y : p.z); };
+    ICP_OUT out;
+    Matrix4d T_all = Matrix4d::Identity();
+    std::vector<KNeighbor> nb_list(row);
+    double prev_error = 0, mean_error = 0;
+    int iter = 0;
+    for (iter = 0; iter < max_iteration; iter++) {
+        // k_nearest_neighbors (:310-359): the query goes through float (:335-336); distances are squared (nanoflann's L2)
+        for (size_t i = 0; i < 3 * row; i++) q[i] = (double)(float)src[i];
+        kd.k_close(q.data(), row, K, idx.data(), d2.data());
+        for (size_t i = 0; i < row; i++) {
+            KNeighbor& nbr = nb_list[i];
+            nbr.sourceIndex = (int)i;
+            float meanDis = 0.0f;
+            for (int k = 0; k < K; k++) { nbr.targetIndexes[k] = idx[i * K + k]; meanDis += (float)d2[i * K + k]; }
+            nbr.distanceMean = meanDis / K;
+        }
+        fork_order(nb_list);
+        // best_fit_transform (:185-253)
+        const int num = (int)((long long)row * remainPercentage / 100);
+        double cA[3] = {0, 0, 0}, cB[3] = {0, 0, 0};
+        for (int i = 0; i < num; i++) {
+            const int a = nb_list[i].sourceIndex;
+            for (int c = 0; c < 3; c++) cA[c] += src[3 * a + c];
+            for (int k = 0; k < K; k++) for (int c = 0; c < 3; c++) cB[c] += Bp(nb_list[i].targetIndexes[k], c);
+            for (int c = 0; c < 3; c++) cB[c] /= K;              // :205, inside the point loop
+        }
+        for (int c = 0; c < 3; c++) { cA[c] /= num; cB[c] /= num; }
+        Matrix3d H;
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) H(r, c) = 0.0;
+        for (size_t i = 0; i < row; i++) {
+            double aa[3], bb[3];
+            if ((int)i < num) {
+                const int a = nb_list[i].sourceIndex, b = nb_list[i].targetIndexes[K - 1];   // the last neighbour overwrites the others (:216-220)
+                for (int c = 0; c < 3; c++) { aa[c] = src[3 * a + c] - cA[c]; bb[c] = (Bp(b, c) - cB[c]) / K; }
+            } else {
+                for (int c = 0; c < 3; c++) aa[c] = bb[c] = src[3 * i + c];                 // AA = BB = A where the loop does not reach (:192-193)
+            }
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) H(r, c) += aa[r] * bb[c];
+        }
+        Matrix3d U, V, R;
+        double sv[3];
+        svd3(H, U, sv, V);
+        auto make = [&](double sgn) {
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R(r, c) = U(r, 0) * V(c, 0) + U(r, 1) * V(c, 1) + sgn * U(r, 2) * V(c, 2);
+        };
+        make(1.0);
+        if (det3(R) < 0) make(-1.0);
+        Matrix4d T = Matrix4d::Identity();
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) T(r, c) = R(r, c);
+            T(r, 3) = cB[r] - (R(r, 0) * cA[0] + R(r, 1) * cA[1] + R(r, 2) * cA[2]);
+        }
+        T_all = T * T_all;
+        for (size_t i = 0; i < row; i++) { double p[3]; apply4(T, &src[3 * i], p); src[3 * i] = p[0]; src[3 * i + 1] = p[1]; src[3 * i + 2] = p[2]; }
+        mean_error = 0.0;
+        for (size_t i = 0; i < row; i++) mean_error += nb_list[i].distanceMean;
+        mean_error /= (double)row;
+        if (std::fabs(prev_error - mean_error) < tolerance) break;
+        prev_error = mean_error;
+    }
+    out.trans = T_all;
+    out.distances.resize(row);
+    for (size_t i = 0; i < row; i++) out.distances[i] = nb_list[i].distanceMean;
+    out.iter = iter + 1;                                          // :457, also when the loop ran out
+    return out;
+}
+
 // ---- LDT --------------------------------------------------------------------------------------------------
 
 LDT::LDT(const PointCloudTPtr& cloud, uint32_t _div, int _core, DevicePtr d) : div(_div), CORES(_core), dev(d ? d : std::make_shared<Device>(0)), cloud_(cloud) {
@@ -1017,6 +1131,17 @@ int icpxh_kdtree_k_close(void* p, const double* q, size_t n, int k, int32_t* idx
 }
 int icpxh_kdtree_distance(void* p, const float* q, size_t n, float* out) {
     return guard([&] { HKd* h = (HKd*)p; if (n == 1) out[0] = h->kd->Distance(q[0], q[1], q[2]); else h->kd->Distance(q, n, out); });
+}
+
+// ---- the icp/ fork's loop
+int icpxh_knn_icp(int device, const float* A, size_t na, const float* B, size_t nb, int max_iteration, float tolerance, int K, int remain,
+                  double* trans16, float* distances, int* iter) {
+    return guard([&] {
+        const ICP_OUT r = knn_icp(make_cloud(A, na), make_cloud(B, nb), max_iteration, tolerance, K, remain, std::make_shared<Device>(device));
+        std::memcpy(trans16, r.trans.m, 16 * sizeof(double));
+        if (distances) std::memcpy(distances, r.distances.data(), r.distances.size() * sizeof(float));
+        *iter = r.iter;
+    });
 }
 
 // ---- LDT

@@ -136,6 +136,23 @@ public:
     DevicePtr dev;
 };
 
+// The loop of the reference's icp/ fork (icp/src/icp.hpp:398-460) around its k-nearest-neighbour search (:310-359) and its
+// best_fit_transform over K neighbours (:185-253), restated as a function of its input. The fork qsorts a vector of
+// structs that own std::vectors with a comparator that truncates a float difference to int, so what it computes is not
+// determined by its input; here the order is that comparator applied by a stable bottom-up merge sort (with squared
+// distances below 1 it leaves the source order), the K neighbours are the exact nearest by (distance, index), and the
+// arithmetic follows the fork statement by statement: the running "centroid_B /= K" inside the point loop (:205), the
+// row of BB that keeps only the last neighbour (:216-221), the rows beyond `num` that stay copies of A (:192-193,
+// remainPercentage < 100), R = U V^T with the sign fix on V's third column (:240-246). Needs nb <= na, as the fork
+// does (it indexes a matrix of min(na, nb) target points with neighbours found among all nb).
+struct ICP_OUT {            // icp/src/icp.hpp:23-27
+    Matrix4d trans;
+    std::vector<float> distances;   // mean squared distance to the K neighbours per source point, in the sorted order of the last iteration
+    int iter = 0;
+};
+ICP_OUT knn_icp(const PointCloudTPtr& A, const PointCloudTPtr& B, int max_iteration, float tolerance, int Ksearch = 5,
+                int remainPercentage = 100, DevicePtr dev = nullptr);
+
 class LDT {                 // src/testLDT.cpp:26-37
 public:
     LDT(const PointCloudTPtr&, uint32_t _div = 300, int _core = 2, DevicePtr dev = nullptr);

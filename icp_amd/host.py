@@ -40,6 +40,8 @@ def _lib():
         lib.icpxh_icp3d_free.argtypes = [C.c_void_p]; lib.icpxh_icp3d_free.restype = None
         lib.icpxh_icp3d_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_int,
                                         C.c_double, C.c_void_p, C.c_void_p]
+        lib.icpxh_knn_icp.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
         lib.icpxh_goicp_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int]
         lib.icpxh_goicp_exact_residuals.argtypes = [C.c_void_p, C.c_int]
         lib.icpxh_goicp_set_collective_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -214,6 +216,16 @@ class DT3D:
     def __del__(self):
         if getattr(self, "_h", None):
             _lib().icpxh_dt3d_free(self._h); self._h = None
+
+
+def knn_icp(A, B, max_iteration, tolerance, K=5, remain_percentage=100, device=0):
+    """icp::knn_icp: the loop of the reference's icp/ fork (icp/src/icp.hpp:398-460) over K exact nearest neighbours, with a
+    defined order (see icpx_host.hpp). Returns dict(trans [4,4], distances [n] float32 in the last iteration's order, iter)."""
+    A = np.ascontiguousarray(A, np.float32).reshape(-1, 3); B = np.ascontiguousarray(B, np.float32).reshape(-1, 3)
+    trans = np.empty(16); dist = np.empty(min(A.shape[0], B.shape[0]), np.float32); it = C.c_int()
+    _ck(_lib().icpxh_knn_icp(device, _vp(A), A.shape[0], _vp(B), B.shape[0], int(max_iteration), float(tolerance), int(K), int(remain_percentage),
+                             _vp(trans), _vp(dist), C.byref(it)))
+    return dict(trans=trans.reshape(4, 4), distances=dist, iter=it.value)
 
 
 class ICP3D:

@@ -984,6 +984,112 @@ int orc_goicp(const float* model, int64_t nm, const float* data, int64_t nd, dou
     return 0;
 }
 
+// ---- the icp/ fork's K-neighbour loop -----------------------------------------------------------------------
+// icp() of icp/src/icp.hpp:398-460 with k_nearest_neighbors (:310-359) and the K-neighbour best_fit_transform
+// (:185-253), made a function of its input: exact K nearest by (squared distance, index) of the float-rounded query
+// (:335-336), the fork's comparator (:66-71, float difference truncated to int) applied by a stable bottom-up merge
+// sort, and the fork's arithmetic statement by statement. Parity unpinned: the fork itself qsorts structs that own
+// vectors (undefined behaviour), so there is no run of it to compare with.
+int orc_knn_icp(const float* A, int64_t na, const float* B, int64_t nb, int max_iteration, float tolerance, int K, int remain,
+                double* trans16, float* distances, int* iter_out, int threads) {
+    if (na <= 0 || nb <= 0 || nb > na || K < 1 || K > 8 || nb < K) return -1;
+    const int64_t n = nb;
+    std::vector<double> P(3 * n);
+    for (int64_t i = 0; i < 3 * n; i++) P[i] = (double)A[i];
+    std::vector<int32_t> nidx((size_t)n * K), order(n), scratch(n);
+    std::vector<double> nd2((size_t)n * K), qf(3 * n);
+    std::vector<float> mean(n);
+    double Tall[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    double prev = 0.0;
+    int it = 0;
+    for (; it < max_iteration; it++) {
+        for (int64_t i = 0; i < 3 * n; i++) qf[i] = (double)(float)P[i];
+        orc_knn_brute(qf.data(), n, B, nb, K, nidx.data(), nd2.data(), threads);
+        for (int64_t i = 0; i < n; i++) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; k++) acc += (float)nd2[i * K + k];
+            mean[i] = acc / K;
+            order[i] = (int32_t)i;
+        }
+        // merge sort of the source indices, runs doubling; an element of the right run goes first only when the
+        // comparator says "before" ((int)(difference) < 0, i.e. difference <= -1)
+        for (int64_t run = 1; run < n; run <<= 1) {
+            for (int64_t s0 = 0; s0 < n; s0 += 2 * run) {
+                const int64_t m = std::min(s0 + run, n), e = std::min(s0 + 2 * run, n);
+                int64_t l = s0, r = m, o = s0;
+                while (l < m && r < e) {
+                    if (mean[order[r]] - mean[order[l]] <= -1.0f) scratch[o++] = order[r++];
+                    else scratch[o++] = order[l++];
+                }
+                while (l < m) scratch[o++] = order[l++];
+                while (r < e) scratch[o++] = order[r++];
+            }
+            order.swap(scratch);
+        }
+        const int num = (int)(n * remain / 100);
+        double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+        for (int i = 0; i < num; i++) {
+            const int32_t a = order[i];
+            ca[0] += P[3 * a]; ca[1] += P[3 * a + 1]; ca[2] += P[3 * a + 2];
+            for (int k = 0; k < K; k++) {
+                const float* b = B + 3 * (int64_t)nidx[(int64_t)a * K + k];
+                cb[0] += (double)b[0]; cb[1] += (double)b[1]; cb[2] += (double)b[2];
+            }
+            cb[0] /= K; cb[1] /= K; cb[2] /= K;
+        }
+        for (int c = 0; c < 3; c++) { ca[c] /= num; cb[c] /= num; }
+        double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int64_t i = 0; i < n; i++) {
+            double x[3], y[3];
+            if (i < num) {
+                const int32_t a = order[i];
+                const float* b = B + 3 * (int64_t)nidx[(int64_t)a * K + (K - 1)];
+                for (int c = 0; c < 3; c++) { x[c] = P[3 * a + c] - ca[c]; y[c] = ((double)b[c] - cb[c]) / K; }
+            } else {
+                for (int c = 0; c < 3; c++) x[c] = y[c] = P[3 * i + c];
+            }
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) H[r][c] += x[r] * y[c];
+        }
+        double U[3][3], V[3][3], sg[3], R[3][3];
+        svd3(H, U, sg, V);
+        for (int pass = 0; pass < 2; pass++) {
+            const double sgn = pass ? -1.0 : 1.0;
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[r][c] = U[r][0] * V[c][0] + U[r][1] * V[c][1] + sgn * U[r][2] * V[c][2];
+            if (!(det3(R) < 0)) break;
+        }
+        double T[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 1}};
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) T[r][c] = R[r][c];
+            T[r][3] = cb[r] - (R[r][0] * ca[0] + R[r][1] * ca[1] + R[r][2] * ca[2]);
+        }
+        double nxt[4][4];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) {
+            double a = 0.0;
+            for (int k = 0; k < 4; k++) a += T[r][k] * Tall[k][c];
+            nxt[r][c] = a;
+        }
+        std::memcpy(Tall, nxt, sizeof nxt);
+        for (int64_t i = 0; i < n; i++) {
+            double o[3];
+            for (int r = 0; r < 3; r++) {
+                double a = 0.0;
+                a += T[r][0] * P[3 * i]; a += T[r][1] * P[3 * i + 1]; a += T[r][2] * P[3 * i + 2]; a += T[r][3] * 1.0;
+                o[r] = a;
+            }
+            P[3 * i] = o[0]; P[3 * i + 1] = o[1]; P[3 * i + 2] = o[2];
+        }
+        double err = 0.0;
+        for (int64_t i = 0; i < n; i++) err += mean[order[i]];
+        err /= (double)n;
+        if (std::fabs(prev - err) < tolerance) break;
+        prev = err;
+    }
+    std::memcpy(trans16, Tall, sizeof Tall);
+    if (distances) for (int64_t i = 0; i < n; i++) distances[i] = mean[order[i]];
+    *iter_out = it + 1;
+    return 0;
+}
+
 int orc_max_threads() { return omp_get_max_threads(); }
 
 }  // extern "C"

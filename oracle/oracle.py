@@ -162,6 +162,18 @@ def icp3d_run(model, data, max_iter=10000, err_diff=0.000001, do_trim=True, trim
     return dict(R=R.reshape(3, 3), t=t, err=err, iterations=it.value)
 
 
+def knn_icp(A, B, max_iteration, tolerance, K=5, remain_percentage=100, threads=0):
+    """The icp/ fork's loop restated (icp/src/icp.hpp:398-460, :310-359, :185-253) with a defined order.
+    Returns dict(trans [4,4], distances [n] float32, iter)."""
+    A, B = f32(A), f32(B)
+    trans = np.empty(16); dist = np.empty(min(A.shape[0], B.shape[0]), np.float32); it = C.c_int()
+    rc = lib().orc_knn_icp(_vp(A), C.c_int64(A.shape[0]), _vp(B), C.c_int64(B.shape[0]), C.c_int(max_iteration), C.c_float(tolerance),
+                           C.c_int(K), C.c_int(remain_percentage), _vp(trans), _vp(dist), C.byref(it), C.c_int(threads))
+    if rc != 0:
+        raise ValueError("knn_icp: bad arguments")
+    return dict(trans=trans.reshape(4, 4), distances=dist, iter=it.value)
+
+
 # ---- LDT ------------------------------------------------------------------------------------------
 def ldt_box(pts, div):
     pts = f32(pts); mn = np.empty(3, np.float32); cl = C.c_float()

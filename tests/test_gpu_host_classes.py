@@ -245,3 +245,24 @@ def test_goicp_bunny270_against_oracle_golden(bunny000, bun270):
     assert r4["rot_pops"] == r1["rot_pops"] and float(r4["optError"]) == float(r1["optError"]) and r4["lb"] == r1["lb"]
     assert np.array_equal(r4["optMat"], r1["optMat"])
     assert r4["launches"] < r1["launches"]
+
+
+@pytest.mark.parametrize("scale,remain", [(1.0, 100), (100.0, 100), (100.0, 80)])
+def test_knn_icp_against_the_restatement(oracle, scale, remain):
+    """icp::knn_icp (the loop of the reference's icp/ fork, icp/src/icp.hpp:398-460, on icpx_knn) against the CPU restatement:
+    same neighbour sets, same defined order, same statement-by-statement arithmetic, so the per-point mean distances are
+    bit-equal and the transform agrees to the accuracy of the two 3x3 SVDs. At scale 100 the squared distances exceed 1 and
+    the fork's truncating comparator really reorders. Parity unpinned: the fork's own loop is not a function of its input."""
+    from conftest import synth_surface
+    from icp_amd.host import knn_icp
+    B = synth_surface(3000, 1) * np.float32(scale)
+    T = rigid([1, 0.2, 0.1], 3.0, [0.01 * scale, -0.02 * scale, 0.005 * scale])
+    A = ((synth_surface(3500, 2, noise=1e-3).astype(np.float64) * scale) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    ref = oracle.knn_icp(A, B, 12, 1e-9, K=5, remain_percentage=remain)
+    got = knn_icp(A, B, 12, 1e-9, K=5, remain_percentage=remain)
+    assert got["iter"] == ref["iter"]
+    assert np.array_equal(got["distances"], ref["distances"])
+    np.testing.assert_allclose(got["trans"], ref["trans"], rtol=0, atol=1e-9 * max(1.0, scale))
+    from icp_amd import IcpxError
+    with pytest.raises(IcpxError):
+        knn_icp(B, A, 3, 1e-9)          # target larger than source: the fork reads beyond its matrix

@@ -147,3 +147,30 @@ def test_goicp_oracle_runs_bnb_to_a_certificate(oracle, bunny000, bun270):
     r = oracle.goicp(model, data, 2e-2, run_bnb=True, dist_mode=1, sq=sq, mn=mn, cell=cell)
     assert r["optError"] <= r0["optError"] and r["rot_pops"] >= 1
     assert float(r["optError"]) - r["lb"] < data.shape[0] * 2e-2 + 1e-6
+
+
+def test_knn_icp_restatement_is_a_function_of_its_input(oracle):
+    """The icp/ fork's loop restated (oracle.knn_icp): repeatable, the fork's comparator leaves the source order alone
+    while all squared distances are below 1, and reorders at a larger scale. Parity unpinned (see oracle.cpp)."""
+    from conftest import synth_surface, rigid
+    B = synth_surface(1500, 1)
+    T = rigid([1, 0.2, 0.1], 3.0, [0.01, -0.02, 0.005])
+    A = (synth_surface(1800, 2, noise=1e-3).astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    a = oracle.knn_icp(A, B, 6, 1e-9); b = oracle.knn_icp(A, B, 6, 1e-9, threads=1)
+    assert a["iter"] == b["iter"] == 7 and np.array_equal(a["trans"], b["trans"]) and np.array_equal(a["distances"], b["distances"])
+    one = oracle.knn_icp(A, B, 1, 0.0)
+    idx, d2 = oracle.knn_brute(A[:1500].astype(np.float64), B, 5)
+    mean = np.zeros(1500, np.float32)
+    for k in range(5):
+        mean = (mean + d2[:, k].astype(np.float32)).astype(np.float32)
+    assert np.array_equal(one["distances"], mean / np.float32(5))          # source order kept
+    big = oracle.knn_icp(A * np.float32(100), B * np.float32(100), 1, 0.0)
+    idx2, d2b = oracle.knn_brute((A[:1500] * np.float32(100)).astype(np.float64), B * np.float32(100), 5)
+    mean_b = np.zeros(1500, np.float32)
+    for k in range(5):
+        mean_b = (mean_b + d2b[:, k].astype(np.float32)).astype(np.float32)
+    mean_b = mean_b / np.float32(5)
+    assert not np.array_equal(big["distances"], mean_b)                       # reordered ...
+    assert np.array_equal(np.sort(big["distances"]), np.sort(mean_b))          # ... the same values
+    with pytest.raises(ValueError):
+        oracle.knn_icp(B, A, 2, 1e-9)
