@@ -419,18 +419,21 @@ __device__ __forceinline__ void env_finish(const Env<G, POOL>& E, int g, EnvTop&
     if (POOL) E.table(g) = e.tab;
 }
 
-// A wave's 64 lanes read or write one 256-byte piece of a grid row: base (the same in all lanes) + 4 * lane_off,
-// lane_off < 64. As a buffer access the base stays in scalar registers and is advanced by scalar instructions; as a
-// flat pointer the compiler keeps a 64-bit address per lane and spends vector instructions on it at every step.
-// Accesses beyond the 256 bytes would be dropped by the range check; there are none.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_piece(const int* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(base), 0, 256, 0x00020000);
+// A wave's 64 lanes read or write one 256-byte piece of a grid row: base (the same in all lanes) + a scalar byte offset
+// (which row) + 4 * lane_off, lane_off < 64. As a buffer access the base and the row offset stay in scalar registers (one
+// scalar addition per step); as a flat pointer the compiler keeps a 64-bit address per lane and spends vector
+// instructions on it at every step, and a base rebuilt for every row costs half a dozen scalar instructions, which in
+// the read-back loop (seven vector instructions per position) is what the SIMD then waits for. The byte offset of a
+// row is below 2^32 for every grid the library accepts (1022 * 1023^2 * 4). No range check is wanted (all lanes are in
+// range by construction): the descriptor covers the whole address range above its base.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t grid_rows(const int* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(base), 0, -1, 0x00020000);
 }
-__device__ __forceinline__ void row_store(int* base, unsigned lane_off, int v) {
-    __builtin_amdgcn_raw_buffer_store_b32(v, row_piece(base), (int)(lane_off * 4u), 0, 0);
+__device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rows, unsigned row_bytes, unsigned lane_off, int v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rows, (int)(lane_off * 4u), (int)row_bytes, 0);
 }
-__device__ __forceinline__ int row_load(const int* base, unsigned lane_off) {
-    return __builtin_amdgcn_raw_buffer_load_b32(row_piece(base), (int)(lane_off * 4u), 0, 0);
+__device__ __forceinline__ int row_load(__amdgpu_buffer_rsrc_t rows, unsigned row_bytes, unsigned lane_off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(rows, (int)(lane_off * 4u), (int)row_bytes, 0);
 }
 
 // Evaluation cursor on one stack, walking towards position 0.
@@ -493,6 +496,8 @@ __device__ __forceinline__ void env_step_reload(const Env<G, POOL>& E, EnvCur& c
 template <int G, bool POOL, int LO, int N>
 __device__ __forceinline__ void env_span(const Env<G, POOL>& E, EnvCur (&cur)[G], int* __restrict__ out, size_t stride, unsigned lane_off,
                                          int plo, int p) {
+    const __amdgpu_buffer_rsrc_t rows = grid_rows(out);
+    const unsigned stride4 = (unsigned)stride * 4u;
     for (; POOL;) {   // general steps while any cursor of the wave is above the private levels
         bool high = false;
 #pragma unroll
@@ -501,7 +506,7 @@ __device__ __forceinline__ void env_span(const Env<G, POOL>& E, EnvCur (&cur)[G]
         int v = 0x7fffffff;
 #pragma unroll
         for (int j = LO; j < LO + N; j++) v = min(v, env_value(cur[j], p));
-        row_store(out + (size_t)p * stride, lane_off, v + p * p);   // idle lanes shadow the last row: same value, same address
+        row_store(rows, (unsigned)p * stride4, lane_off, v + p * p);   // idle lanes shadow the last row: same value, same address
 #pragma unroll
         for (int j = LO; j < LO + N; j++) {   // only the stacks that are still above pay for the general read-back
             if (__any(cur[j].lvl >= E.cap)) env_step<G, POOL, true>(E, j, cur[j], p);
@@ -514,7 +519,7 @@ __device__ __forceinline__ void env_span(const Env<G, POOL>& E, EnvCur (&cur)[G]
         int v = 0x7fffffff;
 #pragma unroll
         for (int j = LO; j < LO + N; j++) v = min(v, env_value(cur[j], p));
-        row_store(out + (size_t)p * stride, lane_off, v + p * p);   // idle lanes shadow the last row: same value, same address
+        row_store(rows, (unsigned)p * stride4, lane_off, v + p * p);   // idle lanes shadow the last row: same value, same address
 #pragma unroll
         for (int j = LO; j < LO + N; j++) env_step_reload<G, POOL>(E, cur[j], p);
     }
@@ -711,10 +716,12 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restric
         EnvTop e;
         env_init(E, g, e);
         int Gn[PF], Un[PF];
+        const __amdgpu_buffer_rsrc_t planes = grid_rows(plane + rowbase);
+        const unsigned xs4 = (unsigned)xs * 4u;
     #pragma unroll
         for (int j = 0; j < PF; j++) Un[j] = planelist[klo + j];
     #pragma unroll
-        for (int j = 0; j < PF; j++) Gn[j] = row_load(plane + (size_t)Un[j] * xs + rowbase, zl);
+        for (int j = 0; j < PF; j++) Gn[j] = row_load(planes, (unsigned)Un[j] * xs4, zl);
         auto scan = [&](auto safe) {
         for (int k0 = klo; k0 < khi; k0 += PF) {
             int Gc[PF], Uc[PF];
@@ -723,7 +730,7 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restric
     #pragma unroll
             for (int j = 0; j < PF; j++) Un[j] = planelist[k0 + PF + j];
     #pragma unroll
-            for (int j = 0; j < PF; j++) Gn[j] = row_load(plane + (size_t)Un[j] * xs + rowbase, zl);
+            for (int j = 0; j < PF; j++) Gn[j] = row_load(planes, (unsigned)Un[j] * xs4, zl);
     #pragma unroll
             for (int j = 0; j < PF; j++)
                 if (k0 + j < khi) env_add<G, POOL, decltype(safe)::value>(E, g, e, Uc[j], Gc[j], div);
