@@ -467,6 +467,7 @@ struct Mat34 { double m[12]; };
 // k_icp_walk, which continues from the candidate they hold.
 constexpr int TILE_CAP = 512;            // points staged at a time: 8 KiB of LDS (a power of two: slots are packed into TILE_CAP - 1 bits)
 constexpr int TILE_COLS = 256;           // most columns of a box
+constexpr float TILE_NEAR = 2.0f;        // a tile all of whose points have a previous pair nearer than this many cells stages only the cells those pairs bound
 constexpr int TILE_MAX_PTS = 1536;       // most points of a box: a few times the usual number, so that no tile takes many times as long as the others
 constexpr int WALK_SHARDS = 64;          // parts of the walk queue and of the far-tile queue (one wave's lanes read the 64 counts)
 constexpr int BALL_MIN_LANES = 8;        // a tile with at least this many open points goes to k_icp_ball, fewer are walked one by one
@@ -604,14 +605,28 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);
         const int cx = cell_coord((float)p[0], g.minx, g.inv, g.dx), cy = cell_coord((float)p[1], g.miny, g.inv, g.dy),
                   cz = cell_coord((float)p[2], g.minz, g.inv, g.dz);
-        // the tile's box: its cells and one more on every side
-        const int bx0 = max(wave_min(cx) - 1, 0), bx1 = min(wave_max(cx) + 1, g.dx - 1);
-        const int by0 = max(wave_min(cy) - 1, 0), by1 = min(wave_max(cy) + 1, g.dy - 1);
-        const int bz0 = max(wave_min(cz) - 1, 0), bz1 = min(wave_max(cz) + 1, g.dz - 1);
+        const double margin = 1e-3 * h + 1e-6 * (fabs(p[0]) + fabs(p[1]) + fabs(p[2]));
+        // A tile near the surface (every point has a previous pair, less than TILE_NEAR cells away: the converged passes):
+        // a lane's nearest point is no further than that pair, so it lies in the cells that the ball of that radius
+        // around the query touches, two or three per axis for most lanes. Only those cells are staged: the box is their union, and of a
+        // column of the box only the run of cells between the lowest and the highest that some lane asked for (about half
+        // the points of the plain box, whose every column runs the full height). What a lane finds is then final without
+        // the test against the box's faces.
+        const double near2 = (double)TILE_NEAR * h * (double)TILE_NEAR * h;
+        const bool near_tile = __ballot(b.pos >= 0 && b.d2 < near2) == ~0ull;    // idle lanes shadow a real point
+        int lx0 = cx - 1, lx1 = cx + 1, ly0 = cy - 1, ly1 = cy + 1, lz0 = cz - 1, lz1 = cz + 1;   // otherwise: its cells and one more on every side
+        if (near_tile) {
+            const double rr = __dsqrt_rn(b.d2) * (1.0 + 1e-9) + 2.0 * margin;
+            lx0 = cell_coord((float)(p[0] - rr), g.minx, g.inv, g.dx); lx1 = cell_coord((float)(p[0] + rr), g.minx, g.inv, g.dx);
+            ly0 = cell_coord((float)(p[1] - rr), g.miny, g.inv, g.dy); ly1 = cell_coord((float)(p[1] + rr), g.miny, g.inv, g.dy);
+            lz0 = cell_coord((float)(p[2] - rr), g.minz, g.inv, g.dz); lz1 = cell_coord((float)(p[2] + rr), g.minz, g.inv, g.dz);
+        }
+        const int bx0 = max(wave_min(lx0), 0), bx1 = min(wave_max(lx1), g.dx - 1);
+        const int by0 = max(wave_min(ly0), 0), by1 = min(wave_max(ly1), g.dy - 1);
+        const int bz0 = max(wave_min(lz0), 0), bz1 = min(wave_max(lz1), g.dz - 1);
         const int nby = by1 - by0 + 1;
         const long long ncols_ll = (long long)(bx1 - bx0 + 1) * nby;
         const int ncols = (int)min(ncols_ll, (long long)TILE_COLS + 1);
-        const double margin = 1e-3 * h + 1e-6 * (fabs(p[0]) + fabs(p[1]) + fabs(p[2]));
         // squared distance from the query to the nearest place outside the box where a target point could be (nothing
         // lies beyond the grid's own faces)
         double outside = INFINITY;
@@ -625,20 +640,37 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         // Stage the box unless that is clearly wasted: when most lanes already hold a candidate (their previous
         // pair) and hardly any of those is near enough for the box to settle the query.
         const int seeded = __popcll(__ballot(b.pos >= 0)), promising = __popcll(__ballot(b.pos >= 0 && outside > b.d2));
-        bool staged = ncols <= TILE_COLS && !(seeded >= 32 && promising < 8);
+        bool staged = ncols <= TILE_COLS && (near_tile || !(seeded >= 32 && promising < 8));
         int total = 0;
 #ifdef ICPX_NN_STATS
         if (lane == 0) { atomicAdd(&g_nn_stats[0], 1ull); atomicAdd(&g_nn_stats[6], (unsigned long long)ncols); }
 #endif
         wave_sync();                     // the previous tile is done with the column tables
+        // near tile: per column of the box, the lowest and highest cell any lane asked for (in the staging area, which is
+        // free until the points are copied)
+        int* const s_zlo = reinterpret_cast<int*>(s_x);
+        int* const s_zhi = reinterpret_cast<int*>(s_y);
+        if (staged && near_tile) {
+            for (int c = lane; c < ncols; c += 64) { s_zlo[c] = 0x7fffffff; s_zhi[c] = -1; }
+            wave_sync();
+            for (int x = lx0; x <= lx1; x++)
+                for (int y = ly0; y <= ly1; y++) {
+                    const int c = (x - bx0) * nby + (y - by0);
+                    atomicMin(&s_zlo[c], lz0); atomicMax(&s_zhi[c], lz1);
+                }
+            wave_sync();
+        }
         if (staged) {
             for (int c0 = 0; c0 < ncols; c0 += 64) {
                 const int c = c0 + lane;
                 int first = 0, cnt = 0;
                 if (c < ncols) {
                     const size_t cbase = ((size_t)(bx0 + c / nby) * g.dy + (by0 + c % nby)) * g.dz;
-                    first = g.start[cbase + bz0];
-                    cnt = g.start[cbase + bz1 + 1] - first;
+                    const int k0 = near_tile ? s_zlo[c] : bz0, k1 = near_tile ? s_zhi[c] : bz1;
+                    if (k0 <= k1) {
+                        first = g.start[cbase + k0];
+                        cnt = g.start[cbase + k1 + 1] - first;
+                    }
                 }
                 int pre = cnt;               // inclusive prefix sum over the lanes
 #pragma unroll
@@ -727,7 +759,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
                 b.offer(d, __float_as_int(t.w), at);
             }
         }
-        const bool settled = staged && !ambiguous && outside > b.d2;
+        const bool settled = staged && !ambiguous && (near_tile || outside > b.d2);
 #ifdef ICPX_NN_STATS
         if (lane == 0 && tile < (1u << 18)) { g_nn_tile_t[tile] = (unsigned)(wall_clock64() - tile_t0); g_nn_tile_steps[tile] = tile_steps; g_nn_tile_total[tile] = (unsigned)total; }
 #endif
