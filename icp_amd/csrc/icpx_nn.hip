@@ -449,22 +449,22 @@ struct Mat34 { double m[12]; };
 // p = T * [src;1] (multiply then add, k = 0..3 from a zero accumulator) and its nearest target point q, left in seed[]
 // as a position in the sorted target points; k_icp_sums then forms the sums {p, q, p q^T, |p-q|^2}.
 //
-// The source cloud is in Morton order, so the 64 points of a wave fall into a few neighbouring cells. The wave takes
-// the box of those cells plus one cell all round and copies the target points filed under the box into LDS (the box
-// is a set of cell columns along z, each one contiguous run of the sorted points: two reads of cell_start and one
-// run of 16-byte loads per column; TILE_CAP points at a time). Every lane then compares its query with all staged
-// points, read from LDS as broadcasts, in float: with qf = (float)q the float sum
+// The source cloud is in Morton order, so the 64 points of a wave fall into a few neighbouring cells. Every lane names
+// the block of cells it needs (see the kernel: the cells its previous pair bounds, or its own cell and the 26 around it);
+// the wave takes the box that holds all blocks and copies the target points filed under it into LDS (the box is a set of
+// cell columns along z; of each column the run of cells some lane asked for is one contiguous run of the sorted points:
+// two reads of cell_start and one run of 16-byte loads per column; TILE_CAP points at a time). Every lane then compares
+// its query with all staged points, read from LDS as broadcasts, in float: with qf = (float)q the float sum
 // s = dx^2 + dy^2 + dz^2 of float differences satisfies |q - t| >= sqrt(s) (1 - 3.1 u) - u |q|, u = 2^-24 (one
 // rounding of q, one of each difference, three of the sum), so a candidate with s above
 // thr(d) = (sqrt(d) + u (|qx| + |qy| + |qz|))^2 (1 + 2^-20), rounded up to float, is strictly farther than squared
 // distance d and cannot even tie with it. The lane keeps the smallest s, its candidate, and the second smallest s
 // (with a few low bits of s given up to carry the candidate's number, which widens the test by 2^-12);
 // the candidate's exact double distance d then shows, by thr(d), whether any other candidate could be as near
-// (hardly ever one can). What a lane finds is final when no other candidate can and it is nearer than anything
-// outside the box can be (the same test as after the 3x3x3 block of nn_search8). The other lanes (two
-// candidates too close to call in float; queries far from the cloud, as in the first passes of a badly aligned
-// start), and whole tiles whose box has more than TILE_COLS columns or TILE_MAX_PTS points, are queued for
-// k_icp_walk, which continues from the candidate they hold.
+// (hardly ever one can). What a lane finds is final when no other candidate can and nothing outside its block can be
+// nearer. The other lanes (two candidates too close to call in float; queries far from the cloud, as in the first
+// passes of a badly aligned start), and whole tiles whose box has more than TILE_COLS columns or TILE_MAX_PTS points,
+// are left to k_icp_ball or k_icp_walk, which continue from the candidate they hold.
 constexpr int TILE_CAP = 512;            // points staged at a time: 8 KiB of LDS (a power of two: slots are packed into TILE_CAP - 1 bits)
 constexpr int TILE_COLS = 256;           // most columns of a box
 constexpr float TILE_NEAR = 2.0f;        // a tile all of whose points have a previous pair nearer than this many cells stages only the cells those pairs bound
@@ -606,51 +606,50 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         const int cx = cell_coord((float)p[0], g.minx, g.inv, g.dx), cy = cell_coord((float)p[1], g.miny, g.inv, g.dy),
                   cz = cell_coord((float)p[2], g.minz, g.inv, g.dz);
         const double margin = 1e-3 * h + 1e-6 * (fabs(p[0]) + fabs(p[1]) + fabs(p[2]));
-        // A tile near the surface (every point has a previous pair, less than TILE_NEAR cells away: the converged passes):
-        // a lane's nearest point is no further than that pair, so it lies in the cells that the ball of that radius
-        // around the query touches, two or three per axis for most lanes. Only those cells are staged: the box is their union, and of a
-        // column of the box only the run of cells between the lowest and the highest that some lane asked for (about half
-        // the points of the plain box, whose every column runs the full height). What a lane finds is then final without
-        // the test against the box's faces.
+        // What a lane needs staged. With a previous pair less than TILE_NEAR cells away (the converged passes, and a growing
+        // share of the points before that): its nearest point is no further than that pair, so it lies in the cells that
+        // the ball of that radius around the query touches, two or three per axis, and what the lane finds among them is
+        // final. Without one: its own cell and the 26 around it, and what it finds is final only if it is nearer than the
+        // faces of that block. The box staged is the union of the lanes' blocks, and of a column of the box only the run
+        // of cells between the lowest and the highest that some lane asked for (about half the points of a box whose
+        // every column runs the full height).
         const double near2 = (double)TILE_NEAR * h * (double)TILE_NEAR * h;
-        const bool near_tile = __ballot(b.pos >= 0 && b.d2 < near2) == ~0ull;    // idle lanes shadow a real point
-        int lx0 = cx - 1, lx1 = cx + 1, ly0 = cy - 1, ly1 = cy + 1, lz0 = cz - 1, lz1 = cz + 1;   // otherwise: its cells and one more on every side
-        if (near_tile) {
+        const bool near_lane = b.pos >= 0 && b.d2 < near2;
+        int lx0 = max(cx - 1, 0), lx1 = min(cx + 1, g.dx - 1), ly0 = max(cy - 1, 0), ly1 = min(cy + 1, g.dy - 1), lz0 = max(cz - 1, 0), lz1 = min(cz + 1, g.dz - 1);
+        if (near_lane) {
             const double rr = __dsqrt_rn(b.d2) * (1.0 + 1e-9) + 2.0 * margin;
             lx0 = cell_coord((float)(p[0] - rr), g.minx, g.inv, g.dx); lx1 = cell_coord((float)(p[0] + rr), g.minx, g.inv, g.dx);
             ly0 = cell_coord((float)(p[1] - rr), g.miny, g.inv, g.dy); ly1 = cell_coord((float)(p[1] + rr), g.miny, g.inv, g.dy);
             lz0 = cell_coord((float)(p[2] - rr), g.minz, g.inv, g.dz); lz1 = cell_coord((float)(p[2] + rr), g.minz, g.inv, g.dz);
         }
-        const int bx0 = max(wave_min(lx0), 0), bx1 = min(wave_max(lx1), g.dx - 1);
-        const int by0 = max(wave_min(ly0), 0), by1 = min(wave_max(ly1), g.dy - 1);
-        const int bz0 = max(wave_min(lz0), 0), bz1 = min(wave_max(lz1), g.dz - 1);
+        const int bx0 = wave_min(lx0), bx1 = wave_max(lx1), by0 = wave_min(ly0), by1 = wave_max(ly1);
         const int nby = by1 - by0 + 1;
         const long long ncols_ll = (long long)(bx1 - bx0 + 1) * nby;
         const int ncols = (int)min(ncols_ll, (long long)TILE_COLS + 1);
-        // squared distance from the query to the nearest place outside the box where a target point could be (nothing
-        // lies beyond the grid's own faces)
+        // squared distance from the query to the nearest place outside its own block of cells where a target point could be
+        // (nothing lies beyond the grid's own faces)
         double outside = INFINITY;
-        if (bx0 > 0)        { const double t = fmax(p[0] - (ox + bx0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
-        if (bx1 < g.dx - 1) { const double t = fmax(ox + (bx1 + 1) * h - p[0] - margin, 0.0); outside = fmin(outside, t * t); }
-        if (by0 > 0)        { const double t = fmax(p[1] - (oy + by0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
-        if (by1 < g.dy - 1) { const double t = fmax(oy + (by1 + 1) * h - p[1] - margin, 0.0); outside = fmin(outside, t * t); }
-        if (bz0 > 0)        { const double t = fmax(p[2] - (oz + bz0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
-        if (bz1 < g.dz - 1) { const double t = fmax(oz + (bz1 + 1) * h - p[2] - margin, 0.0); outside = fmin(outside, t * t); }
+        if (lx0 > 0)        { const double t = fmax(p[0] - (ox + lx0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
+        if (lx1 < g.dx - 1) { const double t = fmax(ox + (lx1 + 1) * h - p[0] - margin, 0.0); outside = fmin(outside, t * t); }
+        if (ly0 > 0)        { const double t = fmax(p[1] - (oy + ly0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
+        if (ly1 < g.dy - 1) { const double t = fmax(oy + (ly1 + 1) * h - p[1] - margin, 0.0); outside = fmin(outside, t * t); }
+        if (lz0 > 0)        { const double t = fmax(p[2] - (oz + lz0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
+        if (lz1 < g.dz - 1) { const double t = fmax(oz + (lz1 + 1) * h - p[2] - margin, 0.0); outside = fmin(outside, t * t); }
 
         // Stage the box unless that is clearly wasted: when most lanes already hold a candidate (their previous
         // pair) and hardly any of those is near enough for the box to settle the query.
-        const int seeded = __popcll(__ballot(b.pos >= 0)), promising = __popcll(__ballot(b.pos >= 0 && outside > b.d2));
-        bool staged = ncols <= TILE_COLS && (near_tile || !(seeded >= 32 && promising < 8));
+        const int seeded = __popcll(__ballot(b.pos >= 0)), promising = __popcll(__ballot(near_lane || (b.pos >= 0 && outside > b.d2)));
+        bool staged = ncols <= TILE_COLS && !(seeded >= 32 && promising < 8);
         int total = 0;
 #ifdef ICPX_NN_STATS
         if (lane == 0) { atomicAdd(&g_nn_stats[0], 1ull); atomicAdd(&g_nn_stats[6], (unsigned long long)ncols); }
 #endif
         wave_sync();                     // the previous tile is done with the column tables
-        // near tile: per column of the box, the lowest and highest cell any lane asked for (in the staging area, which is
-        // free until the points are copied)
+        // per column of the box, the lowest and highest cell any lane asked for (in the staging area, which is free until
+        // the points are copied)
         int* const s_zlo = reinterpret_cast<int*>(s_x);
         int* const s_zhi = reinterpret_cast<int*>(s_y);
-        if (staged && near_tile) {
+        if (staged) {
             for (int c = lane; c < ncols; c += 64) { s_zlo[c] = 0x7fffffff; s_zhi[c] = -1; }
             wave_sync();
             for (int x = lx0; x <= lx1; x++)
@@ -666,7 +665,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
                 int first = 0, cnt = 0;
                 if (c < ncols) {
                     const size_t cbase = ((size_t)(bx0 + c / nby) * g.dy + (by0 + c % nby)) * g.dz;
-                    const int k0 = near_tile ? s_zlo[c] : bz0, k1 = near_tile ? s_zhi[c] : bz1;
+                    const int k0 = s_zlo[c], k1 = s_zhi[c];
                     if (k0 <= k1) {
                         first = g.start[cbase + k0];
                         cnt = g.start[cbase + k1 + 1] - first;
@@ -759,7 +758,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
                 b.offer(d, __float_as_int(t.w), at);
             }
         }
-        const bool settled = staged && !ambiguous && (near_tile || outside > b.d2);
+        const bool settled = staged && !ambiguous && (near_lane || outside > b.d2);
 #ifdef ICPX_NN_STATS
         if (lane == 0 && tile < (1u << 18)) { g_nn_tile_t[tile] = (unsigned)(wall_clock64() - tile_t0); g_nn_tile_steps[tile] = tile_steps; g_nn_tile_total[tile] = (unsigned)total; }
 #endif
