@@ -854,6 +854,12 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
     const unsigned most = (unsigned)wave_max((int)my_count);
     const unsigned items = most * WALK_SHARDS, group = blockIdx.x & 7u, per_group = (items + 7) / 8;
     const float h = g.h, big = 3e38f;
+    // A tile with a very full or very wide ball is one long job for one wave. With a few far tiles per wave such jobs end up
+    // as the kernel's tail and their points are better walked; with dozens per wave (a cloud of many millions of points far
+    // from its target, whose balls hold four times the points of a million-point cloud's) they average out, and the walk
+    // would take several times longer for them.
+    const bool many = items >= 8u * gridDim.x * TILE_WAVES;
+    const int max_pts = many ? 4 * BALL_MAX_PTS : BALL_MAX_PTS, max_cols = many ? 4 * BALL_MAX_COLS : BALL_MAX_COLS;
 
     for (;;) {
         unsigned taken = 0;
@@ -934,9 +940,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
             const int nby = max(y1 - y0 + 1, 1);
             const long long nc = (long long)max(x1 - x0 + 1, 0) * (long long)max(y1 - y0 + 1, 0);
 #ifdef ICPX_NN_STATS
-            { const unsigned long long k = __popcll(__ballot(sel)); if (lane == 0 && nc > BALL_MAX_COLS) atomicAdd(&g_nn_stats[10], k); }
+            { const unsigned long long k = __popcll(__ballot(sel)); if (lane == 0 && nc > max_cols) atomicAdd(&g_nn_stats[10], k); }
 #endif
-            if (nc > BALL_MAX_COLS) continue;
+            if (nc > max_cols) continue;
             const int ncols = (int)nc;
 
             const float mx = -2.f * (float)ex, my = -2.f * (float)ey, mz = -2.f * (float)ez;
@@ -991,7 +997,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
                 if (nfill == 0 || (!last && nfill <= TILE_COLS - 64)) continue;
                 // the batch: nfill columns, total points
                 staged_pts += total;
-                if (staged_pts > BALL_MAX_PTS) { covered = false; break; }
+                if (staged_pts > max_pts) { covered = false; break; }
                 if (lane == 0) s_pre[nfill] = total;
                 int i1 = -1;                     // list position of the smallest distance, if it is found in this batch
                 for (int lo = 0; lo < total; lo += TILE_CAP) {
