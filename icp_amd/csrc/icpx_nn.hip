@@ -561,8 +561,14 @@ __device__ __forceinline__ size_t icp_tile_of(int tt, int tiles_per_wave) {
 // counter takes about 88 additions per microsecond; an eighth of the tiles of a million points needs 2 000. seed (in / out): per source position, the position of its pair in the sorted target points.
 #ifdef ICPX_NN_STATS
 __device__ unsigned long long g_nn_stats[16];
+__device__ unsigned long long g_ball_t[8];   // wall-clock ticks of k_icp_ball by phase: candidates, geometry, columns, staging, compare, resolve, whole tile
 __device__ unsigned long long g_nn_t0[8192], g_nn_t1[8192];
 __device__ unsigned g_nn_tile_t[1 << 18], g_nn_tile_steps[1 << 18], g_nn_tile_total[1 << 18];
+#endif
+#ifdef ICPX_NN_STATS
+#define BALL_T(k) do { const unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&g_ball_t[k], t_ - t_last); t_last = t_; } while (0)
+#else
+#define BALL_T(k) do { } while (0)
 #endif
 
 __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
@@ -861,9 +867,15 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
     const bool many = items >= 8u * gridDim.x * TILE_WAVES;
     const int max_pts = many ? 4 * BALL_MAX_PTS : BALL_MAX_PTS, max_cols = many ? 4 * BALL_MAX_COLS : BALL_MAX_COLS;
 
+    // (letting a wave whose run is used up go on with the other XCDs' runs moved time between the passes and saved none)
     for (;;) {
         unsigned taken = 0;
-        if (lane == 0) taken = atomicAdd(&qcount[group * 16 + 2], 1u);
+        if (lane == 0) {
+            // a look before the addition: additions to one word go one after the other, and with little to do (the converged
+            // passes) the kernel would last as long as its waves' additions take
+            taken = __hip_atomic_load(&qcount[group * 16 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (taken < per_group) taken = atomicAdd(&qcount[group * 16 + 2], 1u);
+        }
         taken = __shfl(taken, 0);
         const unsigned item = group * per_group + taken;
         if (taken >= per_group || item >= items) break;       // uniform
@@ -871,16 +883,23 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
         if (e >= (unsigned)__shfl((int)my_count, (int)shard)) continue;
         const size_t tile = far_queue[(size_t)shard * tiles_per_shard + e], base = tile * 64;
         const unsigned long long open = far_mask[tile];
+#ifdef ICPX_NN_STATS
+        unsigned long long t_last = wall_clock64();
+        const unsigned long long t_tile = t_last;
+#endif
         const bool mine = (open >> lane) & 1ull;
         const size_t i = base + lane < n ? base + lane : n - 1;
         const float4 s = src[i];
         double p[3];
         icp_transform(T, s, p);
         Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);
+        const bool unpaired = __any(mine && b.pos < 0);
         if (mine && b.pos < 0) greedy_candidate(g, s_loff, p[0], p[1], p[2], b);
-        // the lanes' queries are neighbours: try each other's candidates
+        // The lanes' queries are neighbours: try each other's candidates. Only where some lane came without a previous pair
+        // (the first pass): what a greedy descent finds can be far off, a previous pair hardly is, and the six dependent
+        // reads cost a fifth of a tile's time.
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
+        for (int o = 1; unpaired && o < 64; o <<= 1) {
             const int other = __shfl_xor(b.pos, o);
             if (mine && other >= 0 && other != b.pos) {
                 const float4 t = g.pts[other];
@@ -888,6 +907,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
                 b.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(t.w), other);
             }
         }
+        BALL_T(0);
         const float qx = (float)p[0], qy = (float)p[1], qz = (float)p[2];
         const double r_q = __dsqrt_rn(b.d2);                    // infinite without a candidate (empty target)
         const bool want = mine && r_q < 1e30;
@@ -950,7 +970,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
             int best_at = -1, nfill = 0, total = 0;
             bool covered = true;
             wave_sync();                                        // whoever used the tables before is done with them
-            constexpr int AHEAD = 4;             // rounds of 64 columns whose cell_start reads are in flight together
+            BALL_T(1);
+            constexpr int AHEAD = 8;             // rounds of 64 columns whose cell_start reads are in flight together
             int firsts[AHEAD], ends[AHEAD];
             for (int c0 = 0; c0 < ncols; c0 += 64) {
                 // 64 columns: those that hold points inside the ball join the batch
@@ -996,6 +1017,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
                 const bool last = c0 + 64 >= ncols;
                 if (nfill == 0 || (!last && nfill <= TILE_COLS - 64)) continue;
                 // the batch: nfill columns, total points
+                BALL_T(2);
                 staged_pts += total;
                 if (staged_pts > max_pts) { covered = false; break; }
                 if (lane == 0) s_pre[nfill] = total;
@@ -1006,13 +1028,22 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
                     // a lane per list position: its column by bisection of the prefix sums, then all of the lane's reads at once
                     // (column by column, as k_icp_tile copies its few dozen columns, the reads of the next column would wait for
                     // the LDS writes of this one: a ball has hundreds of short columns)
-                    int src_at[TILE_CAP / 64];
+                    // (the eight bisections of a lane advance in step, so that their LDS reads are in flight together)
+                    int src_at[TILE_CAP / 64], col[TILE_CAP / 64];
+#pragma unroll
+                    for (int r = 0; r < TILE_CAP / 64; r++) col[r] = 0;
+#pragma unroll
+                    for (int step = TILE_COLS / 2; step > 0; step >>= 1) {
+#pragma unroll
+                        for (int r = 0; r < TILE_CAP / 64; r++) {
+                            const int cand = col[r] + step;
+                            if (cand < nfill && s_pre[cand] <= lo + 64 * r + lane) col[r] = cand;
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < TILE_CAP / 64; r++) {
                         const int v = lo + 64 * r + lane;
-                        int cc = 0, top = nfill - 1;
-                        while (cc < top) { const int mid = (cc + top + 1) >> 1; if (s_pre[mid] <= v) cc = mid; else top = mid - 1; }
-                        src_at[r] = v < hi ? s_first[cc] + (v - s_pre[cc]) : -1;
+                        src_at[r] = v < hi ? s_first[col[r]] + (v - s_pre[col[r]]) : -1;
                     }
                     float4 pt[TILE_CAP / 64];
 #pragma unroll
@@ -1026,6 +1057,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
                         }
                     if (lane < ((4 - (m & 3)) & 3)) { s_x[m + lane] = 0.f; s_y[m + lane] = 0.f; s_z[m + lane] = 0.f; s_w[m + lane] = 3e37f; }   // fills the last group of four
                     wave_sync();
+                    BALL_T(3);
                     for (int k = 0; k < m; k += 4) {
                         const float4 X = *reinterpret_cast<const float4*>(s_x + k), Y = *reinterpret_cast<const float4*>(s_y + k),
                                      Z = *reinterpret_cast<const float4*>(s_z + k), W = *reinterpret_cast<const float4*>(s_w + k);
@@ -1038,6 +1070,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
                             u1 = fminf(u1, sf);
                         }
                     }
+                    BALL_T(4);
                 }
                 if (i1 >= 0) {                   // the column of that list position: the last one that starts at or before it
                     int cc = 0, hi = nfill - 1;
@@ -1046,6 +1079,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
                 }
                 nfill = 0; total = 0;
                 wave_sync();                     // the tables are free again
+                BALL_T(5);
             }
 #ifdef ICPX_NN_STATS
             { const unsigned long long k = __popcll(__ballot(sel)); if (lane == 0 && !covered) atomicAdd(&g_nn_stats[11], k); }
@@ -1062,6 +1096,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
         }
         const unsigned long long pend = __ballot(mine && !settled);
 #ifdef ICPX_NN_STATS
+        if (lane == 0) atomicAdd(&g_ball_t[6], wall_clock64() - t_tile);
         const unsigned long long k_near = __popcll(__ballot(mine && !want));
         if (lane == 0) { atomicAdd(&g_nn_stats[2], 1ull); atomicAdd(&g_nn_stats[3], __popcll(pend) < __popcll(open) ? 1ull : 0ull); atomicAdd(&g_nn_stats[4], (unsigned long long)staged_pts);
                          atomicAdd(&g_nn_stats[5], (unsigned long long)__popcll(pend)); atomicAdd(&g_nn_stats[12], k_near); }
@@ -1518,6 +1553,9 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
                 h[2], h[3], (double)h[4] / (h[3] ? h[3] : 1), h[5]);
         fprintf(stderr, "   BALL left: near %llu, part<8 %llu, spread %llu, columns %llu, points %llu\n", h[12], h[8], h[9], h[10], h[11]);
         fprintf(stderr, "   WALKQ %llu\n", h[13]);
+        { unsigned long long bt[8], zz[8] = {0}; hipMemcpyFromSymbol(bt, HIP_SYMBOL(g_ball_t), sizeof bt); hipMemcpyToSymbol(HIP_SYMBOL(g_ball_t), zz, sizeof zz);
+          fprintf(stderr, "   BALLT us per far tile: candidates %.1f geometry %.1f columns %.1f staging %.1f compare %.1f resolve %.1f | tile %.1f\n", bt[0] / 100.0 / (h[2] ? h[2] : 1), bt[1] / 100.0 / (h[2] ? h[2] : 1),
+                  bt[2] / 100.0 / (h[2] ? h[2] : 1), bt[3] / 100.0 / (h[2] ? h[2] : 1), bt[4] / 100.0 / (h[2] ? h[2] : 1), bt[5] / 100.0 / (h[2] ? h[2] : 1), bt[6] / 100.0 / (h[2] ? h[2] : 1)); }
         unsigned long long z[16] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof z);
         static std::vector<unsigned long long> t0(8192), t1(8192);
