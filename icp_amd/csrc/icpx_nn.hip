@@ -467,13 +467,14 @@ struct Mat34 { double m[12]; };
 // are left to k_icp_ball or k_icp_walk, which continue from the candidate they hold.
 constexpr int TILE_CAP = 512;            // points staged at a time: 8 KiB of LDS (a power of two: slots are packed into TILE_CAP - 1 bits)
 constexpr int TILE_COLS = 256;           // most columns of a box
-constexpr float TILE_NEAR = 2.0f;        // a tile all of whose points have a previous pair nearer than this many cells stages only the cells those pairs bound
+constexpr float TILE_NEAR = 2.0f;        // a lane whose previous pair is nearer than this many cells asks only for the cells that pair bounds
 constexpr int TILE_MAX_PTS = 1536;       // most points of a box: a few times the usual number, so that no tile takes many times as long as the others
 constexpr int WALK_SHARDS = 64;          // parts of the walk queue and of the far-tile queue (one wave's lanes read the 64 counts)
 constexpr int BALL_MIN_LANES = 8;        // a tile with at least this many open points goes to k_icp_ball, fewer are walked one by one
 constexpr int BALL_MAX_COLS = 16384;     // most cell columns under a tile's ball; beyond that the points are left to the walk
-constexpr int BALL_MAX_PTS = 16384;      // most points staged for a tile: a tile whose queries lie far apart (the Morton order jumps) has a ball full
-                                         // of points, not a shell; its points are cheaper to walk one by one
+constexpr int BALL_MAX_PTS = 4096;       // most points staged for a tile (16 times as many when far tiles abound): a wave with a fuller ball ends up as
+                                         // the kernel's tail, and its points are cheaper to walk one by one (1 M pair, 30 passes: 25.3 / 23.4 / 22.5 /
+                                         // 22.8 / 23.6 ms with 2 048 / 3 072 / 4 096 / 8 192 / 16 384)
 constexpr float BALL_MIN_REACH = 2.f;    // a query at least this many cells from its candidate counts as far from the surface
 constexpr float BALL_MAX_SPREAD = 12.f;  // most cells from the tile's centre to one of its queries, for the same reason
 
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
     // from its target, whose balls hold four times the points of a million-point cloud's) they average out, and the walk
     // would take several times longer for them.
     const bool many = items >= 8u * gridDim.x * TILE_WAVES;
-    const int max_pts = many ? 4 * BALL_MAX_PTS : BALL_MAX_PTS, max_cols = many ? 4 * BALL_MAX_COLS : BALL_MAX_COLS;
+    const int max_pts = many ? 16 * BALL_MAX_PTS : BALL_MAX_PTS, max_cols = many ? 4 * BALL_MAX_COLS : BALL_MAX_COLS;
 
     // (letting a wave whose run is used up go on with the other XCDs' runs moved time between the passes and saved none)
     for (;;) {
