@@ -204,147 +204,167 @@ def main():
     extra = {}
     roofline_nn = None
     if not args.no_extra:
-        # DT lookup: bunny000 points against the grid
-        q = torch.from_numpy(load_scan("bunny000")).to(dev)
-        qrep = q.repeat(25, 1).contiguous()       # ~1 M queries
-        ctx.edt_lookup(qrep)
-        barrier(); t0 = time.perf_counter()
-        for _ in range(20):
+        try:
+            # DT lookup: bunny000 points against the grid
+            q = torch.from_numpy(load_scan("bunny000")).to(dev)
+            qrep = q.repeat(25, 1).contiguous()       # ~1 M queries
             ctx.edt_lookup(qrep)
-        barrier()
-        el = max_over_ranks(time.perf_counter() - t0)
-        extra["dt_lookup_queries_per_s"] = world * qrep.shape[0] * 20 / el
-
-        # configs[2]: synthetic 1 M x 1 M ICP, query-sharded
-        n = args.nn_points
-        tgt_s = synth_surface(n, 42)
-        src_all = synth_surface(n, 43, noise=1e-3).astype(np.float64)
-        Tm = rigid([1, 1, 1], 10.0, [0.02, -0.01, 0.015])
-        src_all = (src_all @ Tm[:3, :3].T + Tm[:3, 3]).astype(np.float32)
-        lo, hi = rank * n // world, (rank + 1) * n // world
-        ctx2 = Context(local)
-        ctx2.set_target(torch.from_numpy(tgt_s).to(dev))
-        ctx2.set_source(torch.from_numpy(np.ascontiguousarray(src_all[lo:hi])).to(dev))
-        sums = torch.zeros(16, dtype=torch.float64, device=dev)
-        ctx2.set_stream(torch.cuda.current_stream().cuda_stream)
-        iters = 30
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        pass_ms = []
-        from icp_amd.host import kabsch_from_sums
-
-        def icp_iter(T, n_total, c):
-            ev0.record()
-            c.icp_step_async(T, sums)       # on torch's current stream (set_stream above), so the events bracket its kernels
-            ev1.record()
-            if world > 1 and args.backend == "nccl":
-                dist.all_reduce(sums)          # RCCL, same stream as the kernels: no host round trip
-                s = sums.cpu().numpy()
-            elif world > 1:
-                hs = sums.cpu(); dist.all_reduce(hs); s = hs.numpy()
-            else:
-                s = sums.cpu().numpy()
-            pass_ms.append(ev0.elapsed_time(ev1))
-            return kabsch_from_sums(s, n_total) @ T
-
-        T = np.eye(4)
-        barrier(); t0 = time.perf_counter()
-        for _ in range(iters):
-            T = icp_iter(T, n, ctx2)
-        barrier()
-        el = max_over_ranks(time.perf_counter() - t0)
-        extra["icp_1m_iterations_per_s"] = iters / el
-        extra["nn_queries_per_s"] = n * iters / el
-        extra["icp_1m_rot_err_deg"] = float(np.rad2deg(np.arccos(np.clip((np.trace(T[:3, :3] @ Tm[:3, :3]) - 1) / 2, -1, 1))))
-        extra["nn_roofline_frac"] = (36.0 * n + 12.0 * n * world) * iters / el / 1e9 / (HBM_PEAK_GBS * world)
-        extra["icp_1m_pass_ms"] = [round(x, 4) for x in pass_ms]
-        for _ in range(10):                   # ten more passes, converged by now: the steady state of the pass
-            T = icp_iter(T, n, ctx2)
-        conv_ms = float(np.mean(pass_ms[-10:]))
-        alg = 36.0 * (hi - lo) + 12.0 * n      # this rank's queries + the whole target, bytes per pass
-        roofline_nn = {"bound": "hbm", "kernel": "k_icp_tile + k_icp_ball + k_icp_walk + k_icp_sums + k_reduce_sums (one ICP pass, this rank's share)",
-                       "algorithmic_bytes_per_pass": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "first_pass": {"ms": pass_ms[0], "achieved": alg / (pass_ms[0] * 1e-3) / 1e9,
-                                      "frac": alg / (pass_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                       "converged": {"ms": conv_ms, "achieved": alg / (conv_ms * 1e-3) / 1e9,
-                                     "frac": alg / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "queries_per_s": (hi - lo) / (conv_ms * 1e-3)},
-                       "traffic": measured_nn_traffic()}
-        ctx2.close()
-        del tgt_s, src_all
-
-        # configs[4]: the large scan-to-model pair (same generator, seeds 44 / 45), queries sharded over the ranks,
-        # target replicated; ten passes from the 10-degree start
-        if args.big_points:
-            nb = args.big_points
-            tgt_b = synth_surface(nb, 44)
-            lo_b, hi_b = rank * nb // world, (rank + 1) * nb // world
-            src_b = synth_surface(nb, 45, noise=1e-3)[lo_b:hi_b].astype(np.float64)
-            src_b = (src_b @ Tm[:3, :3].T + Tm[:3, 3]).astype(np.float32)
-            ctx3 = Context(local)
-            t0 = time.perf_counter()
-            ctx3.set_target(torch.from_numpy(tgt_b).to(dev))
-            torch.cuda.synchronize()
-            extra["icp_16m_grid_build_s"] = time.perf_counter() - t0
-            ctx3.set_source(torch.from_numpy(np.ascontiguousarray(src_b)).to(dev))
-            ctx3.set_stream(torch.cuda.current_stream().cuda_stream)
-            del tgt_b, src_b
-            Tb = np.eye(4); pass_ms = []
             barrier(); t0 = time.perf_counter()
-            for _ in range(10):
-                Tb = icp_iter(Tb, nb, ctx3)
+            for _ in range(20):
+                ctx.edt_lookup(qrep)
             barrier()
             el = max_over_ranks(time.perf_counter() - t0)
-            extra["icp_16m_points"] = nb
-            extra["icp_16m_iterations_per_s"] = 10 / el
-            extra["icp_16m_queries_per_s"] = nb * 10 / el
-            extra["icp_16m_pass_ms"] = [round(x, 3) for x in pass_ms]
-            extra["icp_16m_rot_err_deg"] = float(np.rad2deg(np.arccos(np.clip((np.trace(Tb[:3, :3] @ Tm[:3, :3]) - 1) / 2, -1, 1))))
-            ctx3.close()
+            extra["dt_lookup_queries_per_s"] = world * qrep.shape[0] * 20 / el
+        except Exception as exc:      # an extra leg must not take the headline line with it
+            import traceback; traceback.print_exc()
+            extra.setdefault("errors", {})["dt_lookup"] = repr(exc)[:300]
 
-        # configs[0], the reference's own run: bunny000 -> bunny045, 30 iterations through the host class
-        # (src/main.cpp:270-284); every rank runs the whole registration
-        from icp_amd.host import SingleThreadIcp
-        st = SingleThreadIcp(load_scan("bunny000"), load_scan("bunny045"), iters=30, device=local)
-        st.registration()
-        barrier(); t0 = time.perf_counter()
-        for _ in range(5):
+        try:
+            # configs[2]: synthetic 1 M x 1 M ICP, query-sharded
+            n = args.nn_points
+            tgt_s = synth_surface(n, 42)
+            src_all = synth_surface(n, 43, noise=1e-3).astype(np.float64)
+            Tm = rigid([1, 1, 1], 10.0, [0.02, -0.01, 0.015])
+            src_all = (src_all @ Tm[:3, :3].T + Tm[:3, 3]).astype(np.float32)
+            lo, hi = rank * n // world, (rank + 1) * n // world
+            ctx2 = Context(local)
+            ctx2.set_target(torch.from_numpy(tgt_s).to(dev))
+            ctx2.set_source(torch.from_numpy(np.ascontiguousarray(src_all[lo:hi])).to(dev))
+            sums = torch.zeros(16, dtype=torch.float64, device=dev)
+            ctx2.set_stream(torch.cuda.current_stream().cuda_stream)
+            iters = 30
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pass_ms = []
+            from icp_amd.host import kabsch_from_sums
+
+            def icp_iter(T, n_total, c):
+                ev0.record()
+                c.icp_step_async(T, sums)       # on torch's current stream (set_stream above), so the events bracket its kernels
+                ev1.record()
+                if world > 1 and args.backend == "nccl":
+                    dist.all_reduce(sums)          # RCCL, same stream as the kernels: no host round trip
+                    s = sums.cpu().numpy()
+                elif world > 1:
+                    hs = sums.cpu(); dist.all_reduce(hs); s = hs.numpy()
+                else:
+                    s = sums.cpu().numpy()
+                pass_ms.append(ev0.elapsed_time(ev1))
+                return kabsch_from_sums(s, n_total) @ T
+
+            T = np.eye(4)
+            barrier(); t0 = time.perf_counter()
+            for _ in range(iters):
+                T = icp_iter(T, n, ctx2)
+            barrier()
+            el = max_over_ranks(time.perf_counter() - t0)
+            extra["icp_1m_iterations_per_s"] = iters / el
+            extra["nn_queries_per_s"] = n * iters / el
+            extra["icp_1m_rot_err_deg"] = float(np.rad2deg(np.arccos(np.clip((np.trace(T[:3, :3] @ Tm[:3, :3]) - 1) / 2, -1, 1))))
+            extra["nn_roofline_frac"] = (36.0 * n + 12.0 * n * world) * iters / el / 1e9 / (HBM_PEAK_GBS * world)
+            extra["icp_1m_pass_ms"] = [round(x, 4) for x in pass_ms]
+            for _ in range(10):                   # ten more passes, converged by now: the steady state of the pass
+                T = icp_iter(T, n, ctx2)
+            conv_ms = float(np.mean(pass_ms[-10:]))
+            alg = 36.0 * (hi - lo) + 12.0 * n      # this rank's queries + the whole target, bytes per pass
+            roofline_nn = {"bound": "hbm", "kernel": "k_icp_tile + k_icp_ball + k_icp_walk + k_icp_sums + k_reduce_sums (one ICP pass, this rank's share)",
+                           "algorithmic_bytes_per_pass": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "first_pass": {"ms": pass_ms[0], "achieved": alg / (pass_ms[0] * 1e-3) / 1e9,
+                                          "frac": alg / (pass_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                           "converged": {"ms": conv_ms, "achieved": alg / (conv_ms * 1e-3) / 1e9,
+                                         "frac": alg / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "queries_per_s": (hi - lo) / (conv_ms * 1e-3)},
+                           "traffic": measured_nn_traffic()}
+            ctx2.close()
+            del tgt_s, src_all
+        except Exception as exc:      # an extra leg must not take the headline line with it
+            import traceback; traceback.print_exc()
+            extra.setdefault("errors", {})["icp_1m"] = repr(exc)[:300]
+
+        try:
+            # configs[4]: the large scan-to-model pair (same generator, seeds 44 / 45), queries sharded over the ranks,
+            # target replicated; ten passes from the 10-degree start
+            if args.big_points:
+                nb = args.big_points
+                tgt_b = synth_surface(nb, 44)
+                lo_b, hi_b = rank * nb // world, (rank + 1) * nb // world
+                src_b = synth_surface(nb, 45, noise=1e-3)[lo_b:hi_b].astype(np.float64)
+                src_b = (src_b @ Tm[:3, :3].T + Tm[:3, 3]).astype(np.float32)
+                ctx3 = Context(local)
+                t0 = time.perf_counter()
+                ctx3.set_target(torch.from_numpy(tgt_b).to(dev))
+                torch.cuda.synchronize()
+                extra["icp_16m_grid_build_s"] = time.perf_counter() - t0
+                ctx3.set_source(torch.from_numpy(np.ascontiguousarray(src_b)).to(dev))
+                ctx3.set_stream(torch.cuda.current_stream().cuda_stream)
+                del tgt_b, src_b
+                Tb = np.eye(4); pass_ms = []
+                barrier(); t0 = time.perf_counter()
+                for _ in range(10):
+                    Tb = icp_iter(Tb, nb, ctx3)
+                barrier()
+                el = max_over_ranks(time.perf_counter() - t0)
+                extra["icp_16m_points"] = nb
+                extra["icp_16m_iterations_per_s"] = 10 / el
+                extra["icp_16m_queries_per_s"] = nb * 10 / el
+                extra["icp_16m_pass_ms"] = [round(x, 3) for x in pass_ms]
+                extra["icp_16m_rot_err_deg"] = float(np.rad2deg(np.arccos(np.clip((np.trace(Tb[:3, :3] @ Tm[:3, :3]) - 1) / 2, -1, 1))))
+                ctx3.close()
+        except Exception as exc:      # an extra leg must not take the headline line with it
+            import traceback; traceback.print_exc()
+            extra.setdefault("errors", {})["icp_16m"] = repr(exc)[:300]
+
+        try:
+            # configs[0], the reference's own run: bunny000 -> bunny045, 30 iterations through the host class
+            # (src/main.cpp:270-284); every rank runs the whole registration
+            from icp_amd.host import SingleThreadIcp
+            st = SingleThreadIcp(load_scan("bunny000"), load_scan("bunny045"), iters=30, device=local)
             st.registration()
-        barrier()
-        extra["icp_bunny045_30it_ms"] = max_over_ranks(time.perf_counter() - t0) / 5 * 1e3
-        del st
-
-        # configs[3]: Go-ICP on the reference's bunny pair (model bunny000 = bun315/bun000, data bun315/bun270), both
-        # clouds normalised isotropically into [-1,1]^3, DT 300^3, mse 1e-3. The 2 x 8 inner searches of a rotation cube
-        # advance in lock-step, one launch per step (each starts from the optError of the moment the cube is popped,
-        # where the reference's one-after-the-other order lets a later search see an earlier one's improvement);
-        # `lookahead` and `speculate` only put more cubes into a launch, the decisions are those of lookahead = speculate
-        # = 0. With several ranks every launch is shared: each rank evaluates its share on its GPU, the shares are
-        # summed by one all-reduce of the device buffer (RCCL, same stream), every rank takes the same decisions.
-        if not args.no_goicp:
-            from icp_amd.host import GoIcp, normalize_goicp
-            gm, gd, _ = normalize_goicp(load_scan("bunny000"), load_scan("bun270"))
-            kw = {}
-            if world > 1 and args.backend == "nccl":
-                kw = dict(allreduce_dev=lambda t: dist.all_reduce(t), dev_buffer=torch.zeros(1 << 16, dtype=torch.float64, device=dev))
-            elif world > 1:
-                def allreduce_host(a):
-                    t = torch.from_numpy(a); dist.all_reduce(t)
-                kw = dict(allreduce=allreduce_host)
-            go = GoIcp(gm, gd, mse=1e-3, dt_div=DIV, device=local, rank=rank, world=world, **kw)
-            go.options(batched=True, frontier_width=1, lookahead=args.goicp_lookahead, speculate=args.goicp_speculate)
             barrier(); t0 = time.perf_counter()
-            gr = go.registration()
+            for _ in range(5):
+                st.registration()
             barrier()
-            el = max_over_ranks(time.perf_counter() - t0)
-            extra["goicp_bunny270"] = {
-                "time_to_optimum_s": el, "optimal_sse": float(gr["optError"]), "lower_bound": float(gr["lb"]),
-                "epsilon": float(gr["sseThresh"]), "initial_sse": float(gr["initError"]), "icp_sse": float(gr["icpError"]),
-                "rotation_cubes": gr["rot_pops"], "bound_evaluations": gr["inner_evals"], "launches": gr["launches"],
-                "points": int(gd.shape[0]), "order": "inner searches of a rotation cube in lock-step (batched)",
-                "lookahead": args.goicp_lookahead, "speculate": args.goicp_speculate,
-                "searched_ahead_used": gr["spec_hits"], "searched_ahead_discarded": gr["spec_misses"],
-                "collective": "device all-reduce (RCCL) per launch" if (world > 1 and args.backend == "nccl") else
-                              ("host all-reduce per launch" if world > 1 else "none")}
-            del go
+            extra["icp_bunny045_30it_ms"] = max_over_ranks(time.perf_counter() - t0) / 5 * 1e3
+            del st
+        except Exception as exc:      # an extra leg must not take the headline line with it
+            import traceback; traceback.print_exc()
+            extra.setdefault("errors", {})["icp_bunny"] = repr(exc)[:300]
+
+        try:
+            # configs[3]: Go-ICP on the reference's bunny pair (model bunny000 = bun315/bun000, data bun315/bun270), both
+            # clouds normalised isotropically into [-1,1]^3, DT 300^3, mse 1e-3. The 2 x 8 inner searches of a rotation cube
+            # advance in lock-step, one launch per step (each starts from the optError of the moment the cube is popped,
+            # where the reference's one-after-the-other order lets a later search see an earlier one's improvement);
+            # `lookahead` and `speculate` only put more cubes into a launch, the decisions are those of lookahead = speculate
+            # = 0. With several ranks every launch is shared: each rank evaluates its share on its GPU, the shares are
+            # summed by one all-reduce of the device buffer (RCCL, same stream), every rank takes the same decisions.
+            if not args.no_goicp:
+                from icp_amd.host import GoIcp, normalize_goicp
+                gm, gd, _ = normalize_goicp(load_scan("bunny000"), load_scan("bun270"))
+                kw = {}
+                if world > 1 and args.backend == "nccl":
+                    kw = dict(allreduce_dev=lambda t: dist.all_reduce(t), dev_buffer=torch.zeros(1 << 16, dtype=torch.float64, device=dev))
+                elif world > 1:
+                    def allreduce_host(a):
+                        t = torch.from_numpy(a); dist.all_reduce(t)
+                    kw = dict(allreduce=allreduce_host)
+                go = GoIcp(gm, gd, mse=1e-3, dt_div=DIV, device=local, rank=rank, world=world, **kw)
+                go.options(batched=True, frontier_width=1, lookahead=args.goicp_lookahead, speculate=args.goicp_speculate)
+                barrier(); t0 = time.perf_counter()
+                gr = go.registration()
+                barrier()
+                el = max_over_ranks(time.perf_counter() - t0)
+                extra["goicp_bunny270"] = {
+                    "time_to_optimum_s": el, "optimal_sse": float(gr["optError"]), "lower_bound": float(gr["lb"]),
+                    "epsilon": float(gr["sseThresh"]), "initial_sse": float(gr["initError"]), "icp_sse": float(gr["icpError"]),
+                    "rotation_cubes": gr["rot_pops"], "bound_evaluations": gr["inner_evals"], "launches": gr["launches"],
+                    "points": int(gd.shape[0]), "order": "inner searches of a rotation cube in lock-step (batched)",
+                    "lookahead": args.goicp_lookahead, "speculate": args.goicp_speculate,
+                    "searched_ahead_used": gr["spec_hits"], "searched_ahead_discarded": gr["spec_misses"],
+                    "collective": "device all-reduce (RCCL) per launch" if (world > 1 and args.backend == "nccl") else
+                                  ("host all-reduce per launch" if world > 1 else "none")}
+                del go
+        except Exception as exc:      # an extra leg must not take the headline line with it
+            import traceback; traceback.print_exc()
+            extra.setdefault("errors", {})["goicp"] = repr(exc)[:300]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
