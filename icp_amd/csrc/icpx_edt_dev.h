@@ -2,39 +2,46 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// (int)(a / cell) for a >= 0 with the division rounded to nearest, as the reference computes it. The product with the
-// rounded reciprocal is within 2e-7 (relative) of that quotient; unless it lies within 1e-6 of an integer both
-// truncate to the same cell, and the division itself is only done for the few values that do.
-static __device__ __forceinline__ int edt_cell_of(float a, float cell, float inv) {
-    const float q = __fmul_rn(a, inv);
-    if (fabsf(q - rintf(q)) > q * 1e-6f) return (int)q;
-    return (int)__fdiv_rn(a, cell);
-}
-
-// LDT::Distance, src/testLDT.cpp:235-290: clamp (recording the overshoot in double), float index
-// arithmetic (the overshoot too is a float difference widened to double), g * cellLen in float, + sqrt(overshoot^2) in double, result rounded to float.
+// LDT::Distance, src/testLDT.cpp:235-290: clamp (recording the overshoot), float index arithmetic, g * cellLen in
+// float, + sqrt(overshoot^2) in double, result rounded to float.
+//
+// The cell of a coordinate is (int)(a / cell) with the division rounded to nearest, as the reference computes it. The
+// product with the rounded reciprocal is within 2e-7 (relative) of that quotient; unless it lies within 1e-6 of an
+// integer both truncate to the same cell. The division itself is done only in waves where some lane has such a value
+// (a branch on the whole wave: left to the compiler, the rare case was turned into selects and every lane paid for
+// three divisions on every call). The overshoot is kept as the float difference the reference forms and widened to
+// double only outside the box; the voxel is read through a buffer descriptor with a 32-bit offset (a grid of at most
+// 1023^3 voxels has fewer than 2^32 bytes).
 static __device__ __forceinline__ float edt_distance(const int* __restrict__ sq, int div, float mnx, float mny, float mnz, float cell,
                                               float x, float y, float z) {
-    double dx = 0.0, dy = 0.0, dz = 0.0;
     const float fdiv = (float)div;
     const float mxx = __fadd_rn(mnx, __fmul_rn(cell, fdiv));
     const float mxy = __fadd_rn(mny, __fmul_rn(cell, fdiv));
     const float mxz = __fadd_rn(mnz, __fmul_rn(cell, fdiv));
-    if (x < mnx) { dx = (double)__fsub_rn(mnx, x); x = mnx; }
-    if (x > mxx) { dx = (double)__fsub_rn(x, mxx); x = mxx; }
-    if (y < mny) { dy = (double)__fsub_rn(mny, y); y = mny; }
-    if (y > mxy) { dy = (double)__fsub_rn(y, mxy); y = mxy; }
-    if (z < mnz) { dz = (double)__fsub_rn(mnz, z); z = mnz; }
-    if (z > mxz) { dz = (double)__fsub_rn(z, mxz); z = mxz; }
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    if (x < mnx) { ox = __fsub_rn(mnx, x); x = mnx; }
+    if (x > mxx) { ox = __fsub_rn(x, mxx); x = mxx; }
+    if (y < mny) { oy = __fsub_rn(mny, y); y = mny; }
+    if (y > mxy) { oy = __fsub_rn(y, mxy); y = mxy; }
+    if (z < mnz) { oz = __fsub_rn(mnz, z); z = mnz; }
+    if (z > mxz) { oz = __fsub_rn(z, mxz); z = mxz; }
     const float inv = __frcp_rn(cell);
-    int ix = edt_cell_of(__fsub_rn(x, mnx), cell, inv);
-    int iy = edt_cell_of(__fsub_rn(y, mny), cell, inv);
-    int iz = edt_cell_of(__fsub_rn(z, mnz), cell, inv);
-    ix = min(max(ix, 0), div - 1); iy = min(max(iy, 0), div - 1); iz = min(max(iz, 0), div - 1);
-    const float g = __builtin_sqrtf((float)sq[((size_t)ix * div + iy) * div + iz]);
+    const float ax = __fsub_rn(x, mnx), ay = __fsub_rn(y, mny), az = __fsub_rn(z, mnz);
+    float qx = __fmul_rn(ax, inv), qy = __fmul_rn(ay, inv), qz = __fmul_rn(az, inv);
+    const bool cx = !(fabsf(qx - rintf(qx)) > qx * 1e-6f), cy = !(fabsf(qy - rintf(qy)) > qy * 1e-6f), cz = !(fabsf(qz - rintf(qz)) > qz * 1e-6f);
+    if (__any(cx || cy || cz)) {
+        if (cx) qx = __fdiv_rn(ax, cell);
+        if (cy) qy = __fdiv_rn(ay, cell);
+        if (cz) qz = __fdiv_rn(az, cell);
+    }
+    const int ix = min(max((int)qx, 0), div - 1), iy = min(max((int)qy, 0), div - 1), iz = min(max((int)qz, 0), div - 1);
+    const unsigned voxel = ((unsigned)ix * (unsigned)div + (unsigned)iy) * (unsigned)div + (unsigned)iz;
+    const __amdgpu_buffer_rsrc_t grid = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(sq), 0, -1, 0x00020000);
+    const float g = __builtin_sqrtf((float)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(voxel * 4u), 0, 0));
     const float inside = __fmul_rn(g, cell);
-    // inside the box the overshoot is 0 and the double arithmetic below returns `inside` unchanged
-    if (dx == 0.0 && dy == 0.0 && dz == 0.0) return inside;
+    // inside the box the overshoot is 0 and the double arithmetic below would return `inside` unchanged
+    if (ox == 0.f && oy == 0.f && oz == 0.f) return inside;
+    const double dx = (double)ox, dy = (double)oy, dz = (double)oz;
     const double over = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
     return (float)__dadd_rn((double)inside, __dsqrt_rn(over));
 }
