@@ -56,13 +56,19 @@ __global__ __launch_bounds__(256) void k_bnb_eval(EdtView e, const float4* __res
     const size_t per = (n + nsplit - 1) / nsplit;
     const size_t lo = (size_t)split * per, hi = lo + per < n ? lo + per : n;
     double ub = 0.0, lb = 0.0;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const float4 p = data[i];
+    // the next point and its rotation uncertainty are read while this one is looked up
+    size_t i = lo + threadIdx.x;
+    float4 p_next = i < hi ? data[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float mr_next = mr && i < hi ? mr[i] : 0.f;
+    for (; i < hi; i += blockDim.x) {
+        const float4 p = p_next;
+        const float mr_i = mr_next;
+        if (i + blockDim.x < hi) { p_next = data[i + blockDim.x]; if (mr) mr_next = mr[i + blockDim.x]; }
         const float rx = it.R[0] * p.x + it.R[1] * p.y + it.R[2] * p.z;
         const float ry = it.R[3] * p.x + it.R[4] * p.y + it.R[5] * p.z;
         const float rz = it.R[6] * p.x + it.R[7] * p.y + it.R[8] * p.z;
         float d = edt_distance(e.sq, e.div, e.mnx, e.mny, e.mnz, e.cell, rx + tx, ry + ty, rz + tz);
-        if (mr) d -= mr[i];
+        if (mr) d -= mr_i;
         if (d < 0) d = 0;
         if (mindis) mindis[(size_t)item * n + __float_as_int(p.w)] = d;
         ub += (double)(d * d);

@@ -12,6 +12,20 @@
 // three divisions on every call). The overshoot is kept as the float difference the reference forms and widened to
 // double only outside the box; the voxel is read through a buffer descriptor with a 32-bit offset (a grid of at most
 // 1023^3 voxels has fewer than 2^32 bytes).
+// sqrtf of a voxel's squared distance (an integer below 2^22, as a float), correctly rounded like the reference's: the
+// hardware's approximation (within one unit in the last place) and a step to the neighbour below or above where the
+// remainder says so. This is the compiler's own expansion of a correctly rounded sqrtf without the rescaling of tiny
+// arguments and the zero / infinity / NaN cases, none of which an integer in that range needs (0 comes out as 0: the
+// neighbour below is NaN and compares false, the one above leaves a remainder that is not positive).
+static __device__ __forceinline__ float edt_sqrt_of_int(float a) {
+    float s = __builtin_amdgcn_sqrtf(a);
+    const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_below = __builtin_fmaf(-below, s, a), r_above = __builtin_fmaf(-above, s, a);
+    if (r_below <= 0.f) s = below;
+    if (r_above > 0.f) s = above;
+    return s;
+}
+
 static __device__ __forceinline__ float edt_distance(const int* __restrict__ sq, int div, float mnx, float mny, float mnz, float cell,
                                               float x, float y, float z) {
     const float fdiv = (float)div;
@@ -37,7 +51,7 @@ static __device__ __forceinline__ float edt_distance(const int* __restrict__ sq,
     const int ix = min(max((int)qx, 0), div - 1), iy = min(max((int)qy, 0), div - 1), iz = min(max((int)qz, 0), div - 1);
     const unsigned voxel = ((unsigned)ix * (unsigned)div + (unsigned)iy) * (unsigned)div + (unsigned)iz;
     const __amdgpu_buffer_rsrc_t grid = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(sq), 0, -1, 0x00020000);
-    const float g = __builtin_sqrtf((float)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(voxel * 4u), 0, 0));
+    const float g = edt_sqrt_of_int((float)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(voxel * 4u), 0, 0));
     const float inside = __fmul_rn(g, cell);
     // inside the box the overshoot is 0 and the double arithmetic below would return `inside` unchanged
     if (ox == 0.f && oy == 0.f && oz == 0.f) return inside;
