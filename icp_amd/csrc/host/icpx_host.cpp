@@ -5,6 +5,9 @@
 #include "icpx_io.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <queue>
@@ -661,6 +664,10 @@ void GoIcp::eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub
     if (n == 0) return;
     inner_evals += (long long)n;
     launches++;
+    struct Stopwatch {
+        double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~Stopwatch() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    } watch{eval_seconds};
     size_t lo = 0, hi = n;
     if (comm.world > 1) { lo = n * comm.rank / comm.world; hi = n * (comm.rank + 1) / comm.world; }
     std::vector<double> both(2 * n, 0.0);
@@ -865,6 +872,7 @@ static bool rotation_of(float v1, float v2, float v3, float R[9]) {
 
 float GoIcp::OuterBnB() {
     rot_pops = inner_evals = launches = 0;
+    eval_seconds = 0;
 
     // initial error: identity pose, sequential float sum (src/GoIcp.cpp:159-172)
     {
@@ -1029,6 +1037,8 @@ float GoIcp::OuterBnB() {
         if (finished) break;
     }
     spec_misses += (long long)ahead_of_time.size();
+    if (std::getenv("ICPX_GOICP_VERBOSE"))
+        std::fprintf(stderr, "GoIcp: %lld launches, %lld bound evaluations, %.3f s inside the batches\n", launches, inner_evals, eval_seconds);
     return optError;
 }
 

@@ -324,6 +324,7 @@ public:
     Collective comm;              // world > 1: every bound batch is split over the ranks
     // statistics
     long long rot_pops = 0, inner_evals = 0, launches = 0;
+    double eval_seconds = 0;      // wall time spent inside the bound batches (launch, collective, copy back) of the last OuterBnB
     float initError = 0, icpError = 0;
     double final_lb = 0;
     DevicePtr dev;

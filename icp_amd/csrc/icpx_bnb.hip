@@ -26,6 +26,8 @@ struct EdtView {
     const int* __restrict__ sq;
     int div;
     float mnx, mny, mnz, cell;
+    const unsigned short* __restrict__ bricks;   // the same values in bricks of 4 x 4 x 4 voxels (see k_edt_bricks), or NULL
+    int nb;                                      // bricks per axis
 };
 
 // norm in float (the SQ() macro multiplies floats and std::sqrt picks the float overload,
@@ -41,10 +43,11 @@ __global__ void k_maxrotdist(const float4* __restrict__ data, size_t n, RotConst
     for (int l = 0; l < ICPX_MAXROTLEVEL; l++) out[(size_t)l * n + i] = (float)__dmul_rn(rc.c[l], (double)nrm);
 }
 
-__global__ __launch_bounds__(256) void k_bnb_eval(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
-                                                  const icpx_bnb_item* __restrict__ items, int nsplit, double* __restrict__ partials,
-                                                  float* __restrict__ mindis) {
-    const int item = blockIdx.x, split = blockIdx.y;
+// Bounds of one item over one slice of the cloud: every thread adds its points lo + t, lo + t + 256, ... in that order,
+// then the wave's 64 sums by a butterfly, then the four waves as (0 + 1) + (2 + 3). k_bnb_eval8 adds in the same order.
+static __device__ __forceinline__ void bnb_eval_item(const EdtView& e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
+                                                     const icpx_bnb_item* __restrict__ items, int item, int split, int nsplit,
+                                                     double* __restrict__ partials, float* __restrict__ mindis, double (*sm)[4]) {
     const icpx_bnb_item it = items[item];
     const float half = it.w / 2;
     const float tx = it.x + half, ty = it.y + half, tz = it.z + half;
@@ -76,13 +79,191 @@ __global__ __launch_bounds__(256) void k_bnb_eval(EdtView e, const float4* __res
         if (dis > 0) lb += (double)(dis * dis);
     }
     for (int o = 32; o > 0; o >>= 1) { ub += __shfl_xor(ub, o); lb += __shfl_xor(lb, o); }
-    __shared__ double sm[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                      // a previous item's sums have been read
     if (lane == 0) { sm[0][wave] = ub; sm[1][wave] = lb; }
     __syncthreads();
     if (threadIdx.x < 2) {
         const double v = (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
         partials[((size_t)item * nsplit + split) * 2 + threadIdx.x] = bad_level ? (double)NAN : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bnb_eval(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
+                                                  const icpx_bnb_item* __restrict__ items, int nsplit, double* __restrict__ partials,
+                                                  float* __restrict__ mindis) {
+    __shared__ double sm[2][4];
+    bnb_eval_item(e, data, n, maxrot, items, blockIdx.x, blockIdx.y, nsplit, partials, mindis, sm);
+}
+
+// The squared distances once more as 16-bit values in bricks of 4 x 4 x 4 voxels, one 128-byte line each: element
+// ((bx nb + by) nb + bz) 64 + (x & 3) 16 + (y & 3) 4 + (z & 3) with b = voxel >> 2. The 64 neighbouring points of a wave
+// fall into a few bricks where they touch some sixty lines of the [x][y][z] grid, and the bound kernel is limited by
+// the number of lines its lookups touch. Values of 65535 and more are stored as 65535, which sends the reader to the
+// 32-bit grid (voxels more than 255 cells from the surface).
+#define EDT_BRICK_ESCAPE 65535u
+__global__ void k_edt_bricks(const int* __restrict__ sq, int div, int nb, unsigned short* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)nb * nb * nb * 64;
+    if (e >= total) return;
+    const unsigned b = (unsigned)(e >> 6), in = (unsigned)(e & 63);
+    const unsigned bz = b % nb, by = b / nb % nb, bx = b / nb / nb;
+    const unsigned x = bx * 4 + (in >> 4), y = by * 4 + (in >> 2 & 3), z = bz * 4 + (in & 3);
+    unsigned v = EDT_BRICK_ESCAPE;
+    if (x < (unsigned)div && y < (unsigned)div && z < (unsigned)div) {
+        const unsigned w = (unsigned)sq[((size_t)x * div + y) * div + z];
+        v = w < EDT_BRICK_ESCAPE ? w : EDT_BRICK_ESCAPE;
+    }
+    out[e] = (unsigned short)v;
+}
+
+static __device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
+
+// Eight items per workgroup. The eight children of a translation cube (src/GoIcp.cpp:391-401) share the rotation, the
+// level and the width, and each of their coordinates takes one of two values: the rotated point, its rotation
+// uncertainty and the six (coordinate, axis) cell computations are then done once for all eight, and only the voxel
+// lookup and the bound arithmetic per child. Which items form such a family is read off the items themselves (a
+// comparison of bits, the same in every lane); any other eight items, and the last items of a batch whose size is no
+// multiple of eight, are evaluated one after the other as k_bnb_eval does. Every value is computed by the same float
+// operations on the same operands as there and added in the same order, so the bounds are the same bits.
+template <bool BRICKS>
+__global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
+                                                   const icpx_bnb_item* __restrict__ items, int nitems, int nsplit, double* __restrict__ partials,
+                                                   float* __restrict__ mindis) {
+    __shared__ double sm[2][4];
+    __shared__ double sm8[16][4];
+    const int first = blockIdx.x * 8, split = blockIdx.y;
+    const int cnt = nitems - first < 8 ? nitems - first : 8;
+    bool family = cnt == 8;
+    if (family) {
+        const icpx_bnb_item a = items[first];
+        family = a.level < ICPX_MAXROTLEVEL;
+        for (int j = 1; j < 8; j++) {
+            const icpx_bnb_item b = items[first + j];
+            bool same = b.level == a.level && same_bits(b.w, a.w);
+            for (int k = 0; k < 9; k++) same = same && same_bits(b.R[k], a.R[k]);
+            same = same && same_bits(b.x, items[first + (j & 1)].x) && same_bits(b.y, items[first + (j & 2)].y) && same_bits(b.z, items[first + (j & 4)].z);
+            family = family && same;
+        }
+    }
+    if (!family) {
+        for (int k = 0; k < cnt; k++) bnb_eval_item(e, data, n, maxrot, items, first + k, split, nsplit, partials, mindis, sm);
+        return;
+    }
+    const icpx_bnb_item it = items[first];
+    const float half = it.w / 2;
+    const float tx[2] = {it.x + half, items[first + 1].x + half};
+    const float ty[2] = {it.y + half, items[first + 2].y + half};
+    const float tz[2] = {it.z + half, items[first + 4].z + half};
+    const float maxTransDis = (float)(GOICP_SQRT3 / 2.0 * (double)it.w);
+    const float* mr = it.level >= 0 ? maxrot + (size_t)it.level * n : nullptr;
+    const float fdiv = (float)e.div;
+    const float mxx = __fadd_rn(e.mnx, __fmul_rn(e.cell, fdiv)), mxy = __fadd_rn(e.mny, __fmul_rn(e.cell, fdiv)), mxz = __fadd_rn(e.mnz, __fmul_rn(e.cell, fdiv));
+    const float inv = __frcp_rn(e.cell);
+    const __amdgpu_buffer_rsrc_t grid = edt_grid_rsrc(e.sq);
+    const __amdgpu_buffer_rsrc_t bricks = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(e.bricks), 0, -1, 0x00020000);
+    const size_t per = (n + nsplit - 1) / nsplit;
+    const size_t lo = (size_t)split * per, hi = lo + per < n ? lo + per : n;
+    double ub[8], lb[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) ub[j] = lb[j] = 0.0;
+    size_t i = lo + threadIdx.x;
+    float4 p_next = i < hi ? data[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float mr_next = mr && i < hi ? mr[i] : 0.f;
+    for (; i < hi; i += blockDim.x) {
+        const float4 p = p_next;
+        const float mr_i = mr_next;
+        if (i + blockDim.x < hi) { p_next = data[i + blockDim.x]; if (mr) mr_next = mr[i + blockDim.x]; }
+        const float rx = it.R[0] * p.x + it.R[1] * p.y + it.R[2] * p.z;
+        const float ry = it.R[3] * p.x + it.R[4] * p.y + it.R[5] * p.z;
+        const float rz = it.R[6] * p.x + it.R[7] * p.y + it.R[8] * p.z;
+        EdtAxis ax[2], ay[2], az[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            ax[s] = edt_axis_begin(rx + tx[s], e.mnx, mxx, inv);
+            ay[s] = edt_axis_begin(ry + ty[s], e.mny, mxy, inv);
+            az[s] = edt_axis_begin(rz + tz[s], e.mnz, mxz, inv);
+        }
+        // the division itself only in waves where some lane needs it (the empty asm keeps the compiler from turning the
+        // branch into six unconditional divisions)
+        if (__any(ax[0].near || ax[1].near || ay[0].near || ay[1].near || az[0].near || az[1].near)) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < 2; s++) { edt_axis_exact(ax[s], e.cell); edt_axis_exact(ay[s], e.cell); edt_axis_exact(az[s], e.cell); }
+        }
+        const unsigned cx[2] = {edt_axis_cell(ax[0], e.div), edt_axis_cell(ax[1], e.div)}, cy[2] = {edt_axis_cell(ay[0], e.div), edt_axis_cell(ay[1], e.div)},
+                       cz[2] = {edt_axis_cell(az[0], e.div), edt_axis_cell(az[1], e.div)};
+        const bool outside = fmaxf(fmaxf(fmaxf(ax[0].over, ax[1].over), fmaxf(ay[0].over, ay[1].over)), fmaxf(az[0].over, az[1].over)) != 0.f;
+        float g[8];
+        if (BRICKS) {
+            // a voxel's place in the brick copy is a sum of one term per axis
+            unsigned xo[2], xyo[4], zo[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                xo[s] = (cx[s] >> 2) * (unsigned)(e.nb * e.nb * 64) + (cx[s] & 3) * 16;
+                zo[s] = (cz[s] >> 2) * 64 + (cz[s] & 3);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) xyo[s] = xo[s & 1] + (cy[s >> 1] >> 2) * (unsigned)(e.nb * 64) + (cy[s >> 1] & 3) * 4;
+            unsigned v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(bricks, (int)((xyo[j & 3] + zo[j >> 2]) * 2u), 0, 0) & 0xffffu;
+            const unsigned top = max(max(max(v[0], v[1]), max(v[2], v[3])), max(max(v[4], v[5]), max(v[6], v[7])));
+            if (__any(top == EDT_BRICK_ESCAPE)) {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (v[j] == EDT_BRICK_ESCAPE)
+                        v[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(((cx[j & 1] * (unsigned)e.div + cy[j >> 1 & 1]) * (unsigned)e.div + cz[j >> 2]) * 4u), 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) g[j] = (float)v[j];
+        } else {
+            unsigned xoff[2], xyoff[4];
+#pragma unroll
+            for (int s = 0; s < 2; s++) xoff[s] = cx[s] * (unsigned)e.div;
+#pragma unroll
+            for (int s = 0; s < 4; s++) xyoff[s] = (xoff[s & 1] + cy[s >> 1]) * (unsigned)e.div;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                g[j] = (float)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)((xyoff[j & 3] + cz[j >> 2]) * 4u), 0, 0);
+        }
+        float d[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) d[j] = __fmul_rn(edt_sqrt_of_int(g[j]), e.cell);
+        if (__any(outside)) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float ox = ax[j & 1].over, oy = ay[j >> 1 & 1].over, oz = az[j >> 2].over;
+                if (ox != 0.f || oy != 0.f || oz != 0.f) {
+                    const double dx = (double)ox, dy = (double)oy, dz = (double)oz;
+                    const double over = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                    d[j] = (float)__dadd_rn((double)d[j], __dsqrt_rn(over));
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float dj = d[j];
+            if (mr) dj -= mr_i;
+            if (dj < 0) dj = 0;
+            if (mindis) mindis[(size_t)(first + j) * n + __float_as_int(p.w)] = dj;
+            ub[j] += (double)(dj * dj);
+            const float dis = fmaxf(dj - maxTransDis, 0.f);      // a term that is not positive adds +0, which leaves the sum as it is
+            lb[j] += (double)(dis * dis);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        for (int o = 32; o > 0; o >>= 1) { ub[j] += __shfl_xor(ub[j], o); lb[j] += __shfl_xor(lb[j], o); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { sm8[2 * j][wave] = ub[j]; sm8[2 * j + 1][wave] = lb[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const double v = (sm8[threadIdx.x][0] + sm8[threadIdx.x][1]) + (sm8[threadIdx.x][2] + sm8[threadIdx.x][3]);
+        partials[((size_t)(first + (threadIdx.x >> 1)) * nsplit + split) * 2 + (threadIdx.x & 1)] = v;
     }
 }
 
@@ -122,6 +303,8 @@ EdtView edt_view(const icpx_ctx* ctx) {
     EdtView e;
     e.sq = ctx->edt_sq.as<int>(); e.div = (int)ctx->div;
     e.mnx = ctx->edt_min[0]; e.mny = ctx->edt_min[1]; e.mnz = ctx->edt_min[2]; e.cell = ctx->edt_cell;
+    e.bricks = ctx->edt_bricks_ready ? ctx->edt_bricks.as<unsigned short>() : nullptr;
+    e.nb = ((int)ctx->div + 3) / 4;
     return e;
 }
 
@@ -216,6 +399,31 @@ static int bnb_pin_reserve(icpx_ctx* ctx, size_t bytes) {
     return ICPX_OK;
 }
 
+// The bound kernel over `nitems` items in device memory: per (item, slice) partial sums into `partials`.
+// Makes the brick copy of the current grid if there is none yet (any EDT build discards it). Allocates on first use.
+static int bnb_bricks_ensure(icpx_ctx* ctx) {
+    if (ctx->edt_bricks_ready) return ICPX_OK;
+    const size_t nb = ((size_t)ctx->div + 3) / 4, total = nb * nb * nb * 64;
+    ICPX_TRY(icpx_reserve(ctx, ctx->edt_bricks, total * sizeof(unsigned short)));
+    hipLaunchKernelGGL(k_edt_bricks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)ctx->edt_sq.as<int>(), (int)ctx->div, (int)nb,
+                       ctx->edt_bricks.as<unsigned short>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_edt_bricks"));
+    ctx->edt_bricks_ready = true;
+    return ICPX_OK;
+}
+
+// The bound kernel over `nitems` items in device memory: per (item, slice) partial sums into `partials`. The kernel
+// that takes eight items per workgroup reads the brick copy of the grid when there is one.
+static void bnb_launch(icpx_ctx* ctx, const icpx_bnb_item* items_dev, size_t nitems, int nsplit, double* partials, float* mindis_dev) {
+    const size_t n = ctx->nd;
+    if (nitems >= ctx->bnb_group_min && nitems >= 8)
+        hipLaunchKernelGGL(ctx->edt_bricks_ready ? k_bnb_eval8<true> : k_bnb_eval8<false>, dim3((unsigned)((nitems + 7) / 8), (unsigned)nsplit), dim3(256), 0,
+                           ctx->stream, edt_view(ctx), ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), items_dev, (int)nitems, nsplit, partials, mindis_dev);
+    else
+        hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nitems, (unsigned)nsplit), dim3(256), 0, ctx->stream, edt_view(ctx),
+                           ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), items_dev, nsplit, partials, mindis_dev);
+}
+
 // Evaluates items[0 .. nitems) — entries first .. first + nitems - 1 of a batch of `total` — into out_dev (2 * total doubles).
 static int bnb_enqueue(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, double* out_dev, float* mindis_dev, size_t total, size_t first) {
     if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_eval: no EDT has been built");
@@ -235,11 +443,10 @@ static int bnb_enqueue(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems,
     ICPX_TRY(bnb_pin_reserve(ctx, items_bytes + 2 * total * sizeof(double)));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (nitems) {
+        if (ctx->bnb_bricks && nitems >= ctx->bnb_group_min && nitems >= 8) ICPX_TRY(bnb_bricks_ensure(ctx));
         std::memcpy(ctx->bnb_pin, items, items_bytes);
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->bnb_items.p, ctx->bnb_pin, items_bytes, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nitems, (unsigned)nsplit), dim3(256), 0, ctx->stream, edt_view(ctx),
-                           ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), ctx->bnb_items.as<icpx_bnb_item>(), nsplit,
-                           ctx->bnb_partials.as<double>(), mindis_dev);
+        bnb_launch(ctx, ctx->bnb_items.as<icpx_bnb_item>(), nitems, nsplit, ctx->bnb_partials.as<double>(), mindis_dev);
     }
     hipLaunchKernelGGL(k_bnb_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bnb_partials.as<double>(),
                        (int)total, (int)first, (int)nitems, nsplit, out_dev);
@@ -307,8 +514,7 @@ extern "C" int icpx_bnb_eval_noalloc(icpx_ctx* ctx, const icpx_bnb_item* items_d
     // Every {ub, lb} slot that k_bnb_reduce reads is written by k_bnb_eval of this same call, so nothing left in the
     // area by an earlier (possibly larger) batch is ever read and no clearing is needed.
     double* part = ctx->bnb_scratch;
-    hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nitems, (unsigned)nsplit), dim3(256), 0, ctx->stream, edt_view(ctx),
-                       ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), items_dev, nsplit, part, (float*)nullptr);
+    bnb_launch(ctx, items_dev, nitems, nsplit, part, nullptr);
     hipLaunchKernelGGL(k_bnb_reduce, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, ctx->stream, part, (int)nitems, 0, (int)nitems, nsplit, out_dev);
     return icpx_launch_check(ctx, "k_bnb_eval (noalloc)");
 }

@@ -86,12 +86,19 @@ struct icpx_ctx {
     DevBuf edt_spill;        // NULL until a build overflowed the LDS stacks: [level - cap][group][row] 8-byte entries
     DevBuf edt_plane;        // div^3 int32: in-plane squared distances (only non-empty planes written)
     DevBuf edt_sq;           // div^3 int32: squared EDT, [x][y][z]
+    DevBuf edt_bricks;       // the same values as uint16 in bricks of 4 x 4 x 4 voxels, for the bound kernel (made on first use after a build)
+    bool edt_bricks_ready = false;
 
     // ---- Go-ICP ---------------------------------------------------------------------------------------
     size_t nd = 0;
     DevBuf data_pts;         // nd x float4 {x, y, z, bits(original index)}, spatially sorted
     DevBuf maxrot;           // ICPX_MAXROTLEVEL x nd float, sorted order
     DevBuf bnb_items, bnb_partials, bnb_mindis;
+    // Batches of at least this many items are evaluated eight items per workgroup (k_bnb_eval8: half the instructions per
+    // cube for the families of eight sibling cubes the search sends, an eighth of the workgroups); smaller ones one item
+    // per workgroup, which fills the chip from 128 items on. Same bounds either way. ICPX_BNB_GROUP_MIN overrides.
+    size_t bnb_group_min = 256;
+    bool bnb_bricks = true;      // false (ICPX_BNB_BRICKS=0): the bound kernel reads the [x][y][z] grid only
     double* pin_sums = nullptr;  // pinned host memory for the ICPX_NSUMS sums of an ICP pass: the reduction kernel writes them there itself
     double* bnb_scratch = nullptr;   // this GPU's address of the fixed partial-sum area of icpx_bnb_eval_noalloc (resolved at icpx_create)
     void* bnb_pin = nullptr;     // pinned host staging of a bound batch: the items going up, then ub / lb coming down

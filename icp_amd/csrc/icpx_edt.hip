@@ -839,6 +839,7 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev, int report) {
     // No clearing here: the census of the previous build left the occupancy bits zero and zeroed this
     // build's counter set (edt_prepare clears everything when the buffers are (re)allocated or resized).
     ctx->edt_epoch ^= 1;
+    ctx->edt_bricks_ready = false;   // the bound kernel's brick copy belongs to the previous grid
     u64* counters = edt_counters(ctx);
     if (ctx->edt_round)
         edt_launch(k_edt_splat_round, dim3((unsigned)((ctx->nt + 255) / 256)), dim3(256), 0, s, ev, 0, (const float*)ctx->tgt_xyz.as<float>(),

@@ -26,6 +26,43 @@ static __device__ __forceinline__ float edt_sqrt_of_int(float a) {
     return s;
 }
 
+// One axis of LDT::Distance in two steps, for callers that look up several voxels per point. edt_axis_begin: the
+// coordinate clamped into the box [mn, mx] (mx = mn + cell * div in float), the overshoot as the float difference the
+// reference forms (mn - v below the box, v - mx above it, else 0; written as a maximum, which selects the same value),
+// the offset a = v - mn and its quotient by the cell as a product with the rounded reciprocal `inv`. `near` says that
+// the product may truncate to another cell than the correctly rounded quotient a / cell, which the caller then has to
+// form (edt_axis_exact) before edt_axis_cell truncates and clamps it.
+struct EdtAxis { float a, q, over; bool near; };
+static __device__ __forceinline__ EdtAxis edt_axis_begin(float v, float mn, float mx, float inv) {
+    EdtAxis r;
+    r.over = fmaxf(fmaxf(__fsub_rn(mn, v), __fsub_rn(v, mx)), 0.f);
+    v = fminf(fmaxf(v, mn), mx);
+    r.a = __fsub_rn(v, mn);
+    r.q = __fmul_rn(r.a, inv);
+    r.near = !(fabsf(r.q - rintf(r.q)) > r.q * 1e-6f);
+    return r;
+}
+static __device__ __forceinline__ void edt_axis_exact(EdtAxis& r, float cell) {
+    if (r.near) r.q = __fdiv_rn(r.a, cell);
+}
+static __device__ __forceinline__ unsigned edt_axis_cell(const EdtAxis& r, int div) { return (unsigned)min(max((int)r.q, 0), div - 1); }
+
+// The rest of LDT::Distance for a voxel given by its byte offset in the grid: g * cellLen in float, plus the length of
+// the overshoot in double where there is one.
+static __device__ __forceinline__ float edt_distance_at(__amdgpu_buffer_rsrc_t grid, unsigned byte_offset, float cell, float ox, float oy, float oz) {
+    const float g = edt_sqrt_of_int((float)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)byte_offset, 0, 0));
+    const float inside = __fmul_rn(g, cell);
+    // inside the box the overshoot is 0 and the double arithmetic below would return `inside` unchanged
+    if (ox == 0.f && oy == 0.f && oz == 0.f) return inside;
+    const double dx = (double)ox, dy = (double)oy, dz = (double)oz;
+    const double over = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+    return (float)__dadd_rn((double)inside, __dsqrt_rn(over));
+}
+
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t edt_grid_rsrc(const int* sq) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(sq), 0, -1, 0x00020000);
+}
+
 static __device__ __forceinline__ float edt_distance(const int* __restrict__ sq, int div, float mnx, float mny, float mnz, float cell,
                                               float x, float y, float z) {
     const float fdiv = (float)div;

@@ -62,3 +62,100 @@ def test_residuals_match_oracle(gpu_ctx, oracle, bunny000, bun270):
         o[:, r] = ((T[r, 0] * p[:, 0] + T[r, 1] * p[:, 1]) + T[r, 2] * p[:, 2]) + T[r, 3]
     want = oracle.ldt_lookup(sq, info["min"], info["cell"], o.astype(np.float32))
     assert np.array_equal(got, want)
+
+
+def _families(rng, nfam, widths):
+    """Translation cubes as the search sends them: the eight children of `nfam` parents, in the reference's child order
+    (src/GoIcp.cpp:391-401: x = parent.x + (j & 1) w, y with bit 1, z with bit 2, all in float)."""
+    cubes = []
+    for _ in range(nfam):
+        px, py, pz = rng.uniform(-0.9, 0.4, 3).astype(np.float32)
+        w = np.float32(rng.choice(widths)) / np.float32(2)
+        for j in range(8):
+            cubes.append([px + np.float32(j & 1) * w, py + np.float32(j >> 1 & 1) * w, pz + np.float32(j >> 2 & 1) * w, w])
+    return np.array(cubes, np.float32)
+
+
+def test_eight_items_per_workgroup_gives_the_same_bits(oracle, bunny000, bun270, monkeypatch):
+    """k_bnb_eval8 (families of eight sibling cubes share the rotated point and the per-axis cell computations) against
+    k_bnb_eval (one item per workgroup): bounds and per-point distances bit for bit, for whole families, for families
+    mixed with unrelated items, for a batch whose size is no multiple of eight, with cubes reaching outside the grid's
+    box; the per-point distances also against the oracle."""
+    from icp_amd.api import Context
+    model, data = _normalise(bunny000, bun270)
+    data = np.ascontiguousarray(data[::4])
+    rng = np.random.default_rng(11)
+    R1 = oracle.goicp_rotmat(np.array([0.4, -1.1, 0.7], np.float32)).reshape(9)
+    R2 = oracle.goicp_rotmat(np.array([-2.0, 0.3, 1.2], np.float32)).reshape(9)
+    fam = _families(rng, 6, [1.0, 0.5, 0.25, 0.0625])
+    w = np.float32(0.0625)      # the first family far out: most of its points leave the grid's box
+    fam[:8] = [[np.float32(-1.6) + np.float32(j & 1) * w, np.float32(-1.5) + np.float32(j >> 1 & 1) * w, np.float32(1.4) + np.float32(j >> 2 & 1) * w, w] for j in range(8)]
+    loose = np.c_[rng.uniform(-0.5, 0.25, (13, 3)), rng.choice([0.5, 0.25, 0.125], 13)].astype(np.float32)
+    cubes = np.concatenate([fam[:16], loose[:8], fam[16:], loose[8:]])        # 48 + 13 = 61 items
+    rots = [R1] * 16 + [R2] * 8 + [R2] * 32 + [R1] * 5
+    levels = [-1] * 8 + [2] * 8 + [0] * 8 + [5] * 16 + [-1] * 16 + [3] * 5
+    # a family whose members differ in level is no family: items 24..31 share everything but the level of the last one
+    levels[31] = 4
+    got = {}
+    for name, group_min, bricks in (("eight", "0", "1"), ("eight, plain grid", "0", "0"), ("one", "1000000000", "1")):
+        monkeypatch.setenv("ICPX_BNB_GROUP_MIN", group_min)
+        monkeypatch.setenv("ICPX_BNB_BRICKS", bricks)
+        ctx = Context(0)
+        try:
+            ctx.set_target(model)
+            ctx.edt_build(300)
+            info = ctx.edt_info(); sq = ctx.edt_read()
+            ctx.goicp_set_data(data)
+            items = ctx.make_items(rots, cubes, levels)
+            got[name] = ctx.bnb_eval(items, want_mindis=True) + ctx.bnb_eval(items)[:2]
+        finally:
+            ctx.close()
+    for other in ("eight, plain grid", "one"):
+        for a, b in zip(got["eight"], got[other]):
+            assert np.array_equal(a, b), other
+    assert np.array_equal(got["eight"][0], got["eight"][3]) and np.array_equal(got["eight"][1], got["eight"][4])   # with and without the per-point output
+    table = oracle.goicp_maxrotdist(data)
+    md = got["eight"][2]
+    for k in range(len(cubes)):
+        rotated = oracle.goicp_rotate(np.asarray(rots[k]).reshape(3, 3), data)
+        mr = None if levels[k] < 0 else table[levels[k]]
+        _, _, rmd = oracle.goicp_bounds(rotated, cubes[k:k + 1], sq, info["min"], info["cell"], maxrot=mr, want_mindis=True)
+        assert np.array_equal(md[k], rmd[0]), k
+    moved = oracle.goicp_rotate(R1.reshape(3, 3), data) + (cubes[0, :3] + cubes[0, 3] / np.float32(2))
+    assert (moved < np.asarray(info["min"], np.float32)).any()                 # the overshoot branch was taken
+
+
+def test_brick_copy_of_the_grid_far_from_the_surface(oracle, monkeypatch):
+    """The bound kernel reads 16-bit copies of the squared distances and goes back to the 32-bit grid where a value does
+    not fit: a thin target in a 400^3 grid has voxels more than 255 cells away. Same bits as the kernel that only knows
+    the 32-bit grid, and per-point distances equal to the oracle's."""
+    from icp_amd.api import Context
+    rng = np.random.default_rng(5)
+    target = np.c_[np.linspace(-0.5, 0.5, 200), rng.normal(0, 1e-3, 200), rng.normal(0, 1e-3, 200)].astype(np.float32)
+    data = rng.uniform(-1.0, 1.0, (6000, 3)).astype(np.float32)
+    R = oracle.goicp_rotmat(np.array([0.05, -0.02, 0.03], np.float32)).reshape(9)
+    cubes = np.concatenate([_families(np.random.default_rng(6), 1, [0.125]) * np.float32([0.05, 0.05, 0.05, 1]), _families(np.random.default_rng(7), 1, [0.5]) * np.float32([0.1, 0.1, 0.1, 1])])
+    got = {}
+    for name, group_min in (("eight", "0"), ("one", "1000000000")):
+        monkeypatch.setenv("ICPX_BNB_GROUP_MIN", group_min)
+        ctx = Context(0)
+        try:
+            ctx.set_target(target)
+            ctx.edt_build(400)
+            info = ctx.edt_info(); sq = ctx.edt_read()
+            ctx.goicp_set_data(data)
+            got[name] = ctx.bnb_eval(ctx.make_items([R] * 16, cubes, [-1] * 8 + [1] * 8), want_mindis=True)
+            # a rebuild discards the copy; the next batch makes it again
+            ctx.edt_build(400)
+            again = ctx.bnb_eval(ctx.make_items([R] * 16, cubes, [-1] * 8 + [1] * 8), want_mindis=True)
+            for a, b in zip(got[name], again):
+                assert np.array_equal(a, b)
+        finally:
+            ctx.close()
+    for a, b in zip(got["eight"], got["one"]):
+        assert np.array_equal(a, b)
+    assert int(sq.max()) > 65535
+    rotated = oracle.goicp_rotate(R.reshape(3, 3), data)
+    _, _, rmd = oracle.goicp_bounds(rotated, cubes[:8], sq, info["min"], info["cell"], maxrot=None, want_mindis=True)
+    assert np.array_equal(got["eight"][2][:8], rmd)
+    assert (rmd > 256 * info["cell"]).any()            # some looked-up voxels are beyond the 16-bit range
