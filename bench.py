@@ -122,8 +122,8 @@ def main():
     ap.add_argument("--nn-points", type=int, default=1_000_000)
     ap.add_argument("--big-points", type=int, default=16_000_000, help="points of the large scan-to-model pair (0 = skip)")
     ap.add_argument("--no-goicp", action="store_true", help="skip the Go-ICP bunny-270 extra")
-    ap.add_argument("--goicp-lookahead", type=int, default=4, help="queued translation cubes whose children are evaluated ahead of time")
-    ap.add_argument("--goicp-speculate", type=int, default=15, help="rotation cubes whose inner searches run ahead of time in the same launches")
+    ap.add_argument("--goicp-lookahead", type=int, default=2, help="queued translation cubes whose children are evaluated ahead of time")
+    ap.add_argument("--goicp-speculate", type=int, default=127, help="rotation cubes whose inner searches run ahead of time in the same launches")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo for CPU-side rehearsal)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -341,7 +341,7 @@ def main():
                 gm, gd, _ = normalize_goicp(load_scan("bunny000"), load_scan("bun270"))
                 kw = {}
                 if world > 1 and args.backend == "nccl":
-                    kw = dict(allreduce_dev=lambda t: dist.all_reduce(t), dev_buffer=torch.zeros(1 << 16, dtype=torch.float64, device=dev))
+                    kw = dict(allreduce_dev=lambda t: dist.all_reduce(t), dev_buffer=torch.zeros(1 << 18, dtype=torch.float64, device=dev))
                 elif world > 1:
                     def allreduce_host(a):
                         t = torch.from_numpy(a); dist.all_reduce(t)

@@ -232,6 +232,30 @@ class Context:
         count = n - first if count is None else count
         self._ck(self._lib.icpx_bnb_eval_async(self._h, C.cast(items, C.c_void_p), n, first, count, C.c_void_p(out_dev.data_ptr())))
 
+    def bnb_submit(self, slot, parents, first=0, count=None, out_dev=None):
+        """icpx_bnb_submit: the eight children of every parent cube in `parents` (make_items records), as batch `slot`."""
+        n = len(parents)
+        count = n - first if count is None else count
+        self._ck(self._lib.icpx_bnb_submit(self._h, slot, C.cast(parents, C.c_void_p), n, first, count,
+                                           C.c_void_p(out_dev.data_ptr()) if out_dev is not None else None))
+        self._pending = getattr(self, "_pending", {})
+        self._pending[slot] = (n, out_dev is None)
+
+    def bnb_fetch(self, slot, out_dev):
+        """icpx_bnb_fetch: the bounds a batch left in out_dev (summed over the ranks meanwhile) come to the host after all."""
+        self._ck(self._lib.icpx_bnb_fetch(self._h, slot, C.c_void_p(out_dev.data_ptr())))
+        self._pending[slot] = (self._pending[slot][0], True)
+
+    def bnb_collect(self, slot):
+        """icpx_bnb_collect: waits for batch `slot`; returns (ub, lb), 8 per parent, when the bounds come to the host."""
+        n, to_host = self._pending.pop(slot)
+        if not to_host:
+            self._ck(self._lib.icpx_bnb_collect(self._h, slot, None, None))
+            return None
+        ub = np.empty(8 * n, np.float64); lb = np.empty(8 * n, np.float64)
+        self._ck(self._lib.icpx_bnb_collect(self._h, slot, ub.ctypes.data_as(C.c_void_p), lb.ctypes.data_as(C.c_void_p)))
+        return ub, lb
+
     def download(self, dev_tensor, nbytes=None):
         """icpx_download: waits for the context's stream, returns the tensor's bytes as a numpy array of its dtype."""
         out = np.empty(tuple(dev_tensor.shape), {8: np.float64, 4: np.int32}[dev_tensor.element_size()])

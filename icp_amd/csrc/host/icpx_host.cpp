@@ -656,6 +656,14 @@ int GoIcp::cur_level_of(const float* maxDistL) const {
     throw IcpxFailure(ICPX_EINVAL, "innerBnB: maxDistL must be NULL or one of maxRotDist[level]");
 }
 
+namespace {
+struct Stopwatch {
+    double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~Stopwatch() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+double g_t_build = 0, g_t_take = 0, g_t_icp = 0;   // ICPX_GOICP_VERBOSE: host time putting batches together, digesting bounds, in runICP
+}  // namespace
+
 // Evaluates a batch of cubes; with several ranks each one evaluates a contiguous slice and the slices
 // are combined by a sum all-reduce (every rank then holds every bound and takes identical decisions).
 void GoIcp::eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub, std::vector<float>& lb) {
@@ -664,10 +672,7 @@ void GoIcp::eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub
     if (n == 0) return;
     inner_evals += (long long)n;
     launches++;
-    struct Stopwatch {
-        double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-        ~Stopwatch() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
-    } watch{eval_seconds};
+    Stopwatch watch{eval_seconds};
     size_t lo = 0, hi = n;
     if (comm.world > 1) { lo = n * comm.rank / comm.world; hi = n * (comm.rank + 1) / comm.world; }
     std::vector<double> both(2 * n, 0.0);
@@ -757,9 +762,78 @@ static TransNode child_of(const TransNode& parent, int j) {
     return node;
 }
 
+// Sends one batch of parent cubes (each stands for its eight children) to slot `slot`. Alone on its GPU the context
+// evaluates it while the caller goes on (icpx_bnb_submit); with several ranks, or with the reference's sequential float
+// sums, the batch is evaluated before this returns and the bounds wait in slot_ub / slot_lb.
+void GoIcp::submit_parents(int slot, const std::vector<icpx_bnb_item>& parents) {
+    const size_t n = parents.size();
+    inner_evals += (long long)(8 * n);
+    launches++;
+    Stopwatch watch{eval_seconds};
+    slot_count[slot] = n;
+    slot_async[slot] = false;
+    const bool dev_collective = comm.world > 1 && comm.allreduce_sum_dev && comm.dev_buffer && comm.dev_capacity >= 64;
+    if (parity_sums || (comm.world > 1 && !dev_collective)) {
+        std::vector<icpx_bnb_item> items;
+        items.reserve(8 * n);
+        for (const icpx_bnb_item& p : parents) {
+            TransNode t; t.x = p.x; t.y = p.y; t.z = p.z; t.w = p.w; t.lb = t.ub = 0;
+            for (int j = 0; j < 8; j++) {
+                const TransNode c = child_of(t, j);
+                icpx_bnb_item it = p;
+                it.x = c.x; it.y = c.y; it.z = c.z; it.w = c.w;
+                items.push_back(it);
+            }
+        }
+        inner_evals -= (long long)(8 * n); launches--;      // eval_items counts them
+        eval_items(items, slot_ub[slot], slot_lb[slot]);
+        return;
+    }
+    if (comm.world > 1) {
+        // every rank evaluates its share of the parents into the same layout (zeros elsewhere), the sum over the ranks
+        // runs on the GPUs on the context's stream, and one copy brings all bounds to the host. Each slot has its half
+        // of the caller's device buffer; a batch that fits it stays in flight (the copy is only enqueued here), a
+        // larger one is done piece by piece before this returns.
+        const size_t half = comm.dev_capacity / 2 / 16 * 16;
+        double* buf = comm.dev_buffer + (size_t)slot * half;
+        const size_t a = n * comm.rank / comm.world, b = n * (comm.rank + 1) / comm.world;
+        if (16 * n <= half) {
+            dev->check(icpx_bnb_submit(dev->ctx(), slot, parents.data(), n, a, b - a, buf));
+            comm.allreduce_sum_dev(buf, (int)(16 * n), comm.user);
+            dev->check(icpx_bnb_fetch(dev->ctx(), slot, buf));
+            slot_async[slot] = true;
+            return;
+        }
+        slot_ub[slot].assign(8 * n, 0.f); slot_lb[slot].assign(8 * n, 0.f);
+        const size_t cap = half / 16;
+        std::vector<double> part;
+        for (size_t c0 = 0; c0 < n; c0 += cap) {
+            const size_t m = std::min(cap, n - c0);
+            const size_t a2 = m * comm.rank / comm.world, b2 = m * (comm.rank + 1) / comm.world;
+            dev->check(icpx_bnb_submit(dev->ctx(), slot, parents.data() + c0, m, a2, b2 - a2, buf));
+            comm.allreduce_sum_dev(buf, (int)(16 * m), comm.user);
+            part.resize(16 * m);
+            dev->check(icpx_download(dev->ctx(), buf, part.data(), 16 * m * sizeof(double)));
+            dev->check(icpx_bnb_collect(dev->ctx(), slot, nullptr, nullptr));
+            for (size_t k = 0; k < 8 * m; k++) { slot_ub[slot][8 * c0 + k] = (float)part[k]; slot_lb[slot][8 * c0 + k] = (float)part[8 * m + k]; }
+        }
+        return;
+    }
+    dev->check(icpx_bnb_submit(dev->ctx(), slot, parents.data(), n, 0, n, nullptr));
+    slot_async[slot] = true;
+}
+
+void GoIcp::collect_parents(int slot, std::vector<float>& ub, std::vector<float>& lb) {
+    if (!slot_async[slot]) { ub.swap(slot_ub[slot]); lb.swap(slot_lb[slot]); return; }
+    Stopwatch watch{eval_seconds};
+    const size_t n = 8 * slot_count[slot];
+    slot_d.resize(2 * n);
+    dev->check(icpx_bnb_collect(dev->ctx(), slot, slot_d.data(), slot_d.data() + n));
+    ub.resize(n); lb.resize(n);
+    for (size_t k = 0; k < n; k++) { ub[k] = (float)slot_d[k]; lb[k] = (float)slot_d[n + k]; }
+}
+
 void GoIcp::run_searches(const std::vector<Search*>& ss) {
-    std::vector<icpx_bnb_item> items;
-    std::vector<float> ub, lb;
     const int width = std::max(1, frontier_width);
     const int ahead = width == 1 ? std::max(0, lookahead) : 0;
     std::vector<size_t> cand;    // look-ahead: heap positions still to visit
@@ -775,10 +849,25 @@ void GoIcp::run_searches(const std::vector<Search*>& ss) {
             s.que.push(node);
         }
     };
-    for (;;) {
-        items.clear();
-        for (Search* sp : ss) {
-            Search& s = *sp;
+    // The searches are independent of each other, so they advance as two groups, each with a batch of its own: while
+    // the GPU evaluates one group's batch (and, with several ranks, sums it over the ranks) the host digests the other's
+    // bounds and puts its next batch together. With a host-side collective or sequential float sums a batch is evaluated
+    // where it is submitted and one group does.
+    const bool host_collective = comm.world > 1 && !(comm.allreduce_sum_dev && comm.dev_buffer && comm.dev_capacity >= 64);
+    const int ngroups = (pipeline && !host_collective && !parity_sums && ss.size() >= 2) ? 2 : 1;
+    struct Group { size_t lo, hi; std::vector<icpx_bnb_item> parents; bool in_flight = false; };
+    Group groups[2];
+    groups[0].lo = 0; groups[0].hi = ngroups == 2 ? ss.size() / 2 : ss.size();
+    groups[1].lo = groups[0].hi; groups[1].hi = ss.size();
+    std::vector<float> ub, lb;
+
+    // The next batch of a group: for every search that still runs, the cube on top of its queue (after those whose
+    // children's bounds are known already) and the cubes looked ahead.
+    auto build = [&](Group& g) {
+        Stopwatch w_{g_t_build};
+        g.parents.clear();
+        for (size_t si = g.lo; si < g.hi; si++) {
+            Search& s = *ss[si];
             s.pending.clear();
             if (s.done) continue;
             // parents whose children were evaluated ahead of time need no launch
@@ -810,20 +899,19 @@ void GoIcp::run_searches(const std::vector<Search*>& ss) {
                     if (!s.ahead.count(key_of(h[i]))) s.pending.push_back(h[i]);
                 }
             }
-            for (const TransNode& parent : s.pending)
-                for (int j = 0; j < 8; j++) {
-                    const TransNode node = child_of(parent, j);
-                    icpx_bnb_item it;
-                    std::memcpy(it.R, s.R, sizeof it.R);
-                    it.x = node.x; it.y = node.y; it.z = node.z; it.w = node.w; it.level = s.level;
-                    items.push_back(it);
-                }
+            for (const TransNode& parent : s.pending) {
+                icpx_bnb_item it;
+                std::memcpy(it.R, s.R, sizeof it.R);
+                it.x = parent.x; it.y = parent.y; it.z = parent.z; it.w = parent.w; it.level = s.level;
+                g.parents.push_back(it);
+            }
         }
-        if (items.empty()) break;
-        eval_items(items, ub, lb);
+    };
+    auto digest = [&](Group& g) {
+        Stopwatch w_{g_t_take};
         size_t pos = 0;
-        for (Search* sp : ss) {
-            Search& s = *sp;
+        for (size_t si = g.lo; si < g.hi; si++) {
+            Search& s = *ss[si];
             const size_t popped = std::min<size_t>(s.pending.size(), (size_t)width);
             for (size_t k = 0; k < s.pending.size(); k++, pos += 8) {
                 if (k < popped) { if (!s.done) take(s, s.pending[k], &ub[pos], &lb[pos]); }   // an earlier parent of this batch may have ended the search
@@ -834,7 +922,20 @@ void GoIcp::run_searches(const std::vector<Search*>& ss) {
                 }
             }
         }
+    };
+    for (int g = 0; g < ngroups; g++) {
+        build(groups[g]);
+        if (!groups[g].parents.empty()) { submit_parents(g, groups[g].parents); groups[g].in_flight = true; }
     }
+    while (groups[0].in_flight || groups[1].in_flight)
+        for (int g = 0; g < ngroups; g++) {
+            if (!groups[g].in_flight) continue;
+            collect_parents(g, ub, lb);
+            groups[g].in_flight = false;
+            digest(groups[g]);
+            build(groups[g]);
+            if (!groups[g].parents.empty()) { submit_parents(g, groups[g].parents); groups[g].in_flight = true; }
+        }
 }
 
 float GoIcp::innerBnB(float* maxDistL, TransNode* transOut) {
@@ -1014,7 +1115,7 @@ float GoIcp::OuterBnB() {
                 optMat(1, 3) = optNodeTrans.y + optNodeTrans.w / 2;
                 optMat(2, 3) = optNodeTrans.z + optNodeTrans.w / 2;
                 tmpMat = optMat;
-                error = runICP(tmpMat);
+                { Stopwatch w_{g_t_icp}; error = runICP(tmpMat); }
                 if (error < optError) { optError = error; optMat = tmpMat; }
                 // drop queued rotation cubes that can no longer improve (src/GoIcp.cpp:317-328)
                 RotQueue keep;
@@ -1038,7 +1139,7 @@ float GoIcp::OuterBnB() {
     }
     spec_misses += (long long)ahead_of_time.size();
     if (std::getenv("ICPX_GOICP_VERBOSE"))
-        std::fprintf(stderr, "GoIcp: %lld launches, %lld bound evaluations, %.3f s inside the batches\n", launches, inner_evals, eval_seconds);
+        std::fprintf(stderr, "GoIcp: %lld launches, %lld bound evaluations, %.3f s inside the batches; build %.3f take %.3f icp %.3f\n", launches, inner_evals, eval_seconds, g_t_build, g_t_take, g_t_icp), g_t_build = g_t_take = g_t_icp = 0;
     return optError;
 }
 
@@ -1286,6 +1387,7 @@ int icpxh_goicp_options(void* p, int run_bnb, int batched, int parity_sums, int 
     return 0;
 }
 int icpxh_goicp_exact_residuals(void* p, int on) { ((HGo*)p)->go->exact_residuals = on != 0; return 0; }
+int icpxh_goicp_pipeline(void* p, int on) { ((HGo*)p)->go->pipeline = on != 0; return 0; }
 // Device-side collective: allreduce_dev sums n doubles at a device address inside [dev_buffer, dev_buffer + capacity) over
 // the ranks, in place, on the stream given here (which the context then uses for everything).
 int icpxh_goicp_set_collective_dev(void* p, int rank, int world, void (*allreduce_dev)(double*, int), double* dev_buffer,

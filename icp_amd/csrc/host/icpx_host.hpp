@@ -320,6 +320,10 @@ public:
     // launches carry (1 + speculate) times as many cubes, which is what several GPUs sharing every launch need.
     int speculate = 0;
     long long spec_hits = 0, spec_misses = 0;
+    // The searches of one step advance as two groups whose bound batches alternate on the GPU: the host digests one
+    // group's bounds while the other group's batch is evaluated (one GPU, device sums). Decisions are unchanged: a
+    // search never looks at another search's state.
+    bool pipeline = true;
     long long max_rot_pops = 0;   // 0 = unlimited
     Collective comm;              // world > 1: every bound batch is split over the ranks
     // statistics
@@ -336,6 +340,12 @@ private:
     int cur_level_of(const float* maxDistL) const;
     void eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub, std::vector<float>& lb);
     void run_searches(const std::vector<Search*>& ss);
+    void submit_parents(int slot, const std::vector<icpx_bnb_item>& parents);
+    void collect_parents(int slot, std::vector<float>& ub, std::vector<float>& lb);
+    std::vector<float> slot_ub[2], slot_lb[2];   // bounds of a batch that was evaluated where it was submitted
+    std::vector<double> slot_d;
+    size_t slot_count[2] = {0, 0};
+    bool slot_async[2] = {false, false};
 };
 
 }  // namespace icp

@@ -117,6 +117,13 @@ extern "C" void icpx_destroy(icpx_ctx* ctx) {
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->bnb_pin) (void)hipHostFree(ctx->bnb_pin);
+    for (BnbSlot& sl : ctx->bnb_slot) {
+        for (DevBuf* b : {&sl.parents, &sl.items, &sl.partials})
+            if (b->p) (void)hipFree(b->p);
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+
+    }
     if (ctx->pin_sums) (void)hipHostFree(ctx->pin_sums);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

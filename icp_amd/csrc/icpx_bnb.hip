@@ -126,35 +126,52 @@ static __device__ __forceinline__ bool same_bits(float a, float b) { return __fl
 // comparison of bits, the same in every lane); any other eight items, and the last items of a batch whose size is no
 // multiple of eight, are evaluated one after the other as k_bnb_eval does. Every value is computed by the same float
 // operations on the same operands as there and added in the same order, so the bounds are the same bits.
-template <bool BRICKS>
+// PARENTS: `items` holds one record per family, the parent cube, and the eight children are formed here as the search
+// forms them (src/GoIcp.cpp:391-401: w' = w / 2, corner + (0 or 1) w' per axis, in float).
+template <bool BRICKS, bool PARENTS>
 __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
                                                    const icpx_bnb_item* __restrict__ items, int nitems, int nsplit, double* __restrict__ partials,
                                                    float* __restrict__ mindis) {
     __shared__ double sm[2][4];
     __shared__ double sm8[16][4];
     const int first = blockIdx.x * 8, split = blockIdx.y;
-    const int cnt = nitems - first < 8 ? nitems - first : 8;
-    bool family = cnt == 8;
-    if (family) {
-        const icpx_bnb_item a = items[first];
-        family = a.level < ICPX_MAXROTLEVEL;
-        for (int j = 1; j < 8; j++) {
-            const icpx_bnb_item b = items[first + j];
-            bool same = b.level == a.level && same_bits(b.w, a.w);
-            for (int k = 0; k < 9; k++) same = same && same_bits(b.R[k], a.R[k]);
-            same = same && same_bits(b.x, items[first + (j & 1)].x) && same_bits(b.y, items[first + (j & 2)].y) && same_bits(b.z, items[first + (j & 4)].z);
-            family = family && same;
+    icpx_bnb_item it;
+    float tx[2], ty[2], tz[2];
+    if (PARENTS) {
+        it = items[blockIdx.x];
+        it.w = it.w * 0.5f;                     // (float)(parent.w / 2.0): exact either way
+        const float half = it.w / 2;
+        tx[0] = it.x + half; tx[1] = (it.x + it.w) + half;
+        ty[0] = it.y + half; ty[1] = (it.y + it.w) + half;
+        tz[0] = it.z + half; tz[1] = (it.z + it.w) + half;
+        if (it.level >= ICPX_MAXROTLEVEL) {    // a level beyond the table: NaN bounds, as in the one-item kernel
+            if (threadIdx.x < 16) partials[((size_t)(first + (threadIdx.x >> 1)) * nsplit + split) * 2 + (threadIdx.x & 1)] = (double)NAN;
+            return;
         }
+    } else {
+        const int cnt = nitems - first < 8 ? nitems - first : 8;
+        bool family = cnt == 8;
+        if (family) {
+            const icpx_bnb_item a = items[first];
+            family = a.level < ICPX_MAXROTLEVEL;
+            for (int j = 1; j < 8; j++) {
+                const icpx_bnb_item b = items[first + j];
+                bool same = b.level == a.level && same_bits(b.w, a.w);
+                for (int k = 0; k < 9; k++) same = same && same_bits(b.R[k], a.R[k]);
+                same = same && same_bits(b.x, items[first + (j & 1)].x) && same_bits(b.y, items[first + (j & 2)].y) && same_bits(b.z, items[first + (j & 4)].z);
+                family = family && same;
+            }
+        }
+        if (!family) {
+            for (int k = 0; k < cnt; k++) bnb_eval_item(e, data, n, maxrot, items, first + k, split, nsplit, partials, mindis, sm);
+            return;
+        }
+        it = items[first];
+        const float half = it.w / 2;
+        tx[0] = it.x + half; tx[1] = items[first + 1].x + half;
+        ty[0] = it.y + half; ty[1] = items[first + 2].y + half;
+        tz[0] = it.z + half; tz[1] = items[first + 4].z + half;
     }
-    if (!family) {
-        for (int k = 0; k < cnt; k++) bnb_eval_item(e, data, n, maxrot, items, first + k, split, nsplit, partials, mindis, sm);
-        return;
-    }
-    const icpx_bnb_item it = items[first];
-    const float half = it.w / 2;
-    const float tx[2] = {it.x + half, items[first + 1].x + half};
-    const float ty[2] = {it.y + half, items[first + 2].y + half};
-    const float tz[2] = {it.z + half, items[first + 4].z + half};
     const float maxTransDis = (float)(GOICP_SQRT3 / 2.0 * (double)it.w);
     const float* mr = it.level >= 0 ? maxrot + (size_t)it.level * n : nullptr;
     const float fdiv = (float)e.div;
@@ -265,6 +282,20 @@ __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __re
         const double v = (sm8[threadIdx.x][0] + sm8[threadIdx.x][1]) + (sm8[threadIdx.x][2] + sm8[threadIdx.x][3]);
         partials[((size_t)(first + (threadIdx.x >> 1)) * nsplit + split) * 2 + (threadIdx.x & 1)] = v;
     }
+}
+
+// The eight children of every parent cube as items of their own, for batches too small to fill the chip eight items
+// per workgroup.
+__global__ void k_bnb_expand(const icpx_bnb_item* __restrict__ parents, int nparents, icpx_bnb_item* __restrict__ items) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nparents * 8) return;
+    icpx_bnb_item it = parents[i >> 3];
+    const int j = i & 7;
+    it.w = it.w * 0.5f;
+    it.x = it.x + (float)(j & 1) * it.w;
+    it.y = it.y + (float)(j >> 1 & 1) * it.w;
+    it.z = it.z + (float)(j >> 2 & 1) * it.w;
+    items[i] = it;
 }
 
 // out: [ub_0 .. ub_{total-1}, lb_0 .. lb_{total-1}]. The partials belong to items first .. first + count - 1 of the batch; the
@@ -416,8 +447,10 @@ static int bnb_bricks_ensure(icpx_ctx* ctx) {
 // that takes eight items per workgroup reads the brick copy of the grid when there is one.
 static void bnb_launch(icpx_ctx* ctx, const icpx_bnb_item* items_dev, size_t nitems, int nsplit, double* partials, float* mindis_dev) {
     const size_t n = ctx->nd;
+    auto eight = k_bnb_eval8<false, false>;
+    if (ctx->edt_bricks_ready) eight = k_bnb_eval8<true, false>;
     if (nitems >= ctx->bnb_group_min && nitems >= 8)
-        hipLaunchKernelGGL(ctx->edt_bricks_ready ? k_bnb_eval8<true> : k_bnb_eval8<false>, dim3((unsigned)((nitems + 7) / 8), (unsigned)nsplit), dim3(256), 0,
+        hipLaunchKernelGGL(eight, dim3((unsigned)((nitems + 7) / 8), (unsigned)nsplit), dim3(256), 0,
                            ctx->stream, edt_view(ctx), ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), items_dev, (int)nitems, nsplit, partials, mindis_dev);
     else
         hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nitems, (unsigned)nsplit), dim3(256), 0, ctx->stream, edt_view(ctx),
@@ -484,6 +517,103 @@ extern "C" int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, si
     if (!items) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_eval_async: items is NULL");
     ICPX_TRY(icpx_bind(ctx));
     return bnb_enqueue(ctx, items + first, count, out_dev, nullptr, nitems, first);
+}
+
+// ---- parent cubes, two batches in flight ------------------------------------------------------------------------
+// A slot owns what one batch in flight needs: pinned host staging (the parents going up, the bounds coming down),
+// the records, partial sums and bounds on the device, and the event that says its bounds have arrived.
+static int bnb_slot_reserve(icpx_ctx* ctx, BnbSlot& sl, size_t nparents, size_t count) {
+    const size_t in_bytes = std::max<size_t>(count, 1) * sizeof(icpx_bnb_item), out_bytes = 16 * nparents * sizeof(double);
+    if (in_bytes + out_bytes > sl.pin_cap) {
+        if (sl.pin) { ICPX_CHECK_HIP(ctx, hipHostFree(sl.pin)); sl.pin = nullptr; sl.pin_cap = 0; }
+        const size_t want = std::max<size_t>((in_bytes + out_bytes) * 2, 1 << 16);
+        ICPX_CHECK_HIP(ctx, hipHostMalloc(&sl.pin, want, hipHostMallocDefault));
+        sl.pin_cap = want;
+    }
+    if (!sl.done) ICPX_CHECK_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    ICPX_TRY(icpx_reserve(ctx, sl.parents, std::max<size_t>(count, 1) * sizeof(icpx_bnb_item)));
+    ICPX_TRY(icpx_reserve(ctx, sl.items, std::max<size_t>(count, 1) * 8 * sizeof(icpx_bnb_item)));
+    ICPX_TRY(icpx_reserve(ctx, sl.partials, std::max<size_t>(count, 1) * 8 * ICPX_BNB_SLICES * 2 * sizeof(double)));
+    return ICPX_OK;
+}
+
+extern "C" int icpx_bnb_submit(icpx_ctx* ctx, int slot, const icpx_bnb_item* parents, size_t nparents, size_t first, size_t count, double* out_dev) {
+    if (!ctx) return ICPX_EINVAL;
+    if (slot < 0 || slot >= ICPX_BNB_SLOTS) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_submit: slot must be 0 .. %d", ICPX_BNB_SLOTS - 1);
+    if (!parents || nparents == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_submit: empty batch");
+    if (first > nparents || count > nparents - first) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_submit: the share [first, first + count) lies outside the batch");
+    if (nparents > 65535u * 2u) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_bnb_submit: more than 131070 parent cubes in one batch");
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_submit: no EDT has been built");
+    if (ctx->nd == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_submit: no data cloud (call icpx_goicp_set_data first)");
+    for (size_t i = first; i < first + count; i++)
+        if (parents[i].level >= ICPX_MAXROTLEVEL) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_submit: parent %zu has level %d >= %d", i, parents[i].level, ICPX_MAXROTLEVEL);
+    ICPX_TRY(icpx_bind(ctx));
+    BnbSlot& sl = ctx->bnb_slot[slot];
+    // the slot's previous batch has been collected, or is abandoned here: its staging area is about to be rewritten
+    if (sl.busy) { ICPX_CHECK_HIP(ctx, hipEventSynchronize(sl.done)); sl.busy = false; }
+    ICPX_TRY(bnb_slot_reserve(ctx, sl, nparents, count));
+    const size_t n = ctx->nd;
+    const int nsplit = bnb_slices(n);
+    const size_t nchild = 8 * count, total = 8 * nparents;
+    const bool eight = nchild >= ctx->bnb_group_min;
+    if (count && ctx->bnb_bricks && eight) ICPX_TRY(bnb_bricks_ensure(ctx));
+    // Both slots share the context's stream: a stream of its own per slot, so that one slot's copies could overlap the
+    // other's kernels, was tried and gained nothing (the loop is limited by the host side of the search).
+    hipStream_t st = ctx->stream;
+    if (count) {
+        std::memcpy(sl.pin, parents + first, count * sizeof(icpx_bnb_item));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sl.parents.p, sl.pin, count * sizeof(icpx_bnb_item), hipMemcpyHostToDevice, st));
+        if (eight) {
+            auto kernel = k_bnb_eval8<false, true>;
+            if (ctx->edt_bricks_ready) kernel = k_bnb_eval8<true, true>;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)count, (unsigned)nsplit), dim3(256), 0, st,
+                               edt_view(ctx), ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), sl.parents.as<icpx_bnb_item>(), (int)nchild, nsplit,
+                               sl.partials.as<double>(), (float*)nullptr);
+        } else {
+            hipLaunchKernelGGL(k_bnb_expand, dim3((unsigned)((nchild + 255) / 256)), dim3(256), 0, st, sl.parents.as<icpx_bnb_item>(), (int)count,
+                               sl.items.as<icpx_bnb_item>());
+            hipLaunchKernelGGL(k_bnb_eval, dim3((unsigned)nchild, (unsigned)nsplit), dim3(256), 0, st, edt_view(ctx), ctx->data_pts.as<float4>(), n,
+                               ctx->maxrot.as<float>(), sl.items.as<icpx_bnb_item>(), nsplit, sl.partials.as<double>(), (float*)nullptr);
+        }
+    }
+    // bounds for the host: the reduction kernel writes them into the pinned staging area itself (behind the records)
+    sl.to_host = out_dev == nullptr;
+    sl.result = reinterpret_cast<double*>(static_cast<char*>(sl.pin) + std::max<size_t>(count, 1) * sizeof(icpx_bnb_item));
+    hipLaunchKernelGGL(k_bnb_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sl.partials.as<double>(), (int)total, (int)(8 * first),
+                       (int)nchild, nsplit, out_dev ? out_dev : sl.result);
+    ICPX_TRY(icpx_launch_check(ctx, "icpx_bnb_submit"));
+    sl.nparents = nparents;
+    ICPX_CHECK_HIP(ctx, hipEventRecord(sl.done, st));
+    sl.busy = true;
+    return ICPX_OK;
+}
+
+extern "C" int icpx_bnb_fetch(icpx_ctx* ctx, int slot, const double* out_dev) {
+    if (!ctx) return ICPX_EINVAL;
+    if (slot < 0 || slot >= ICPX_BNB_SLOTS) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_fetch: slot must be 0 .. %d", ICPX_BNB_SLOTS - 1);
+    BnbSlot& sl = ctx->bnb_slot[slot];
+    if (!sl.busy || sl.to_host) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_fetch: slot %d holds no batch that was submitted with a device buffer", slot);
+    if (!out_dev) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_fetch: out_dev is NULL");
+    ICPX_TRY(icpx_bind(ctx));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sl.result, out_dev, 16 * sl.nparents * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipEventRecord(sl.done, ctx->stream));
+    sl.to_host = true;
+    return ICPX_OK;
+}
+
+extern "C" int icpx_bnb_collect(icpx_ctx* ctx, int slot, double* ub, double* lb) {
+    if (!ctx) return ICPX_EINVAL;
+    if (slot < 0 || slot >= ICPX_BNB_SLOTS) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_collect: slot must be 0 .. %d", ICPX_BNB_SLOTS - 1);
+    BnbSlot& sl = ctx->bnb_slot[slot];
+    if (!sl.busy) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_collect: nothing was submitted to slot %d", slot);
+    ICPX_TRY(icpx_bind(ctx));
+    ICPX_CHECK_HIP(ctx, hipEventSynchronize(sl.done));
+    sl.busy = false;
+    if (!sl.to_host) return ICPX_OK;      // the bounds are in the caller's device buffer
+    if (!ub || !lb) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_collect: ub / lb is NULL");
+    std::memcpy(ub, sl.result, 8 * sl.nparents * sizeof(double));
+    std::memcpy(lb, sl.result + 8 * sl.nparents, 8 * sl.nparents * sizeof(double));
+    return ICPX_OK;
 }
 
 extern "C" int icpx_download(icpx_ctx* ctx, const void* dev, void* host, size_t bytes) {

@@ -19,6 +19,19 @@ struct DevBuf {
 
 struct EnvTune { int groups, cap, chunks; };
 
+// One bound batch in flight (icpx_bnb_submit / icpx_bnb_collect).
+#define ICPX_BNB_SLOTS 2
+struct BnbSlot {
+    void* pin = nullptr;         // pinned host memory: the parent cubes going up, behind them the bounds coming down
+    size_t pin_cap = 0;
+    DevBuf parents, items, partials;
+    hipEvent_t done = nullptr;   // recorded behind the batch's last command
+    bool busy = false;           // submitted and not collected yet
+    bool to_host = false;        // the bounds come back through `pin` (else they stay in the caller's device buffer)
+    size_t nparents = 0;
+    double* result = nullptr;    // where in `pin` the bounds arrive
+};
+
 struct icpx_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -101,6 +114,7 @@ struct icpx_ctx {
     bool bnb_bricks = true;      // false (ICPX_BNB_BRICKS=0): the bound kernel reads the [x][y][z] grid only
     double* pin_sums = nullptr;  // pinned host memory for the ICPX_NSUMS sums of an ICP pass: the reduction kernel writes them there itself
     double* bnb_scratch = nullptr;   // this GPU's address of the fixed partial-sum area of icpx_bnb_eval_noalloc (resolved at icpx_create)
+    BnbSlot bnb_slot[ICPX_BNB_SLOTS];
     void* bnb_pin = nullptr;     // pinned host staging of a bound batch: the items going up, then ub / lb coming down
     size_t bnb_pin_cap = 0;
 

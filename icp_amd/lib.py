@@ -57,6 +57,9 @@ ICPX_SYMBOLS = {
     "icpx_goicp_read_maxrotdist": (C.c_int, [C.c_void_p, C.c_void_p]),
     "icpx_bnb_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "icpx_bnb_eval_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "icpx_bnb_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "icpx_bnb_collect": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "icpx_bnb_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "icpx_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "icpx_bnb_eval_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "icpx_goicp_residuals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -206,6 +206,25 @@ int icpx_bnb_eval(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, doub
  * GoIcp::innerBnB (src/GoIcp.cpp:381-431). */
 int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems, size_t first, size_t count, double* out_dev);
 
+/* The search loop's form of the same evaluation: a record is a PARENT translation cube (x, y, z, w its corner and side,
+ * R and level as above) and stands for its eight children in the order of GoIcp::innerBnB's child loop
+ * (src/GoIcp.cpp:391-401: side w / 2, corner + (j & 1, j >> 1 & 1, j >> 2 & 1) * side, in float), so a batch goes up as an
+ * eighth of the records; the bounds are those icpx_bnb_eval gives for the eight children, bit for bit. Two batches can
+ * be in flight, one per slot (0 or 1): icpx_bnb_submit copies the records, enqueues the work on the context's stream
+ * and returns; icpx_bnb_collect waits for that slot's batch alone and hands out ub / lb, 8 * nparents doubles each
+ * (host), child j of parent p at 8 p + j. While one batch is evaluated the caller can digest the other's bounds.
+ * This context evaluates parents first .. first + count - 1 of the batch (first = 0, count = nparents: all of it).
+ * out_dev == NULL: the bounds come back to the host through icpx_bnb_collect. out_dev != NULL (DEVICE memory,
+ * 16 * nparents doubles [ub..., lb...]): they are left there, zeros for the other parents' children, for a sum over
+ * the ranks on the same stream as with icpx_bnb_eval_async; icpx_bnb_collect then only waits (ub / lb may be NULL).
+ * Submitting to a slot whose batch was not collected waits for that batch and drops its bounds. */
+int icpx_bnb_submit(icpx_ctx* ctx, int slot, const icpx_bnb_item* parents, size_t nparents, size_t first, size_t count, double* out_dev);
+int icpx_bnb_collect(icpx_ctx* ctx, int slot, double* ub, double* lb);
+/* For a batch that was submitted with a device buffer: enqueues, behind whatever the caller has put on the context's
+ * stream since (the sum over the ranks), the copy of out_dev's 16 * nparents doubles to the host, so that
+ * icpx_bnb_collect waits for that copy and hands out ub / lb as for a batch submitted with out_dev == NULL. */
+int icpx_bnb_fetch(icpx_ctx* ctx, int slot, const double* out_dev);
+
 /* Waits for the context's stream and copies `bytes` of device memory to host memory (results of the _async entry
  * points that the caller left in its own device buffers). No counterpart in the reference. */
 int icpx_download(icpx_ctx* ctx, const void* dev, void* host, size_t bytes);

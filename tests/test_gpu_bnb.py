@@ -159,3 +159,70 @@ def test_brick_copy_of_the_grid_far_from_the_surface(oracle, monkeypatch):
     _, _, rmd = oracle.goicp_bounds(rotated, cubes[:8], sq, info["min"], info["cell"], maxrot=None, want_mindis=True)
     assert np.array_equal(got["eight"][2][:8], rmd)
     assert (rmd > 256 * info["cell"]).any()            # some looked-up voxels are beyond the 16-bit range
+
+
+def _children(parents_xyzw):
+    """The eight children of every parent cube in the reference's order and float arithmetic (src/GoIcp.cpp:391-401)."""
+    out = []
+    for x, y, z, w in parents_xyzw.astype(np.float32):
+        cw = np.float32(w / 2.0)
+        for j in range(8):
+            out.append([x + np.float32(j & 1) * cw, y + np.float32(j >> 1 & 1) * cw, z + np.float32(j >> 2 & 1) * cw, cw])
+    return np.array(out, np.float32)
+
+
+@pytest.mark.parametrize("group_min", ["0", "1000000000"])
+def test_parent_batches_in_two_slots(oracle, bunny000, bun270, monkeypatch, group_min):
+    """icpx_bnb_submit / icpx_bnb_collect: parent cubes stand for their eight children; two batches in flight; a share of
+    a batch into a device buffer. Bounds bit for bit those of icpx_bnb_eval on the children, through either kernel."""
+    import torch
+    from icp_amd.api import Context
+    model, data = _normalise(bunny000, bun270)
+    data = np.ascontiguousarray(data[::4])
+    rng = np.random.default_rng(21)
+    Rs = [oracle.goicp_rotmat(rng.uniform(-1.5, 1.5, 3).astype(np.float32)).reshape(9) for _ in range(3)]
+    monkeypatch.setenv("ICPX_BNB_GROUP_MIN", group_min)
+    ctx = Context(0)
+    try:
+        ctx.set_target(model)
+        ctx.edt_build(300)
+        ctx.goicp_set_data(data)
+        batches = []
+        for np_, seed in ((37, 1), (5, 2), (64, 3)):
+            r = np.random.default_rng(seed)
+            par = np.c_[r.uniform(-0.9, 0.3, (np_, 3)), r.choice([1.0, 0.5, 0.25, 0.03125], np_)].astype(np.float32)
+            par[0] = [-0.5, -0.5, -0.5, 1.0]                      # the root cube of every inner search
+            rots = [Rs[k % 3] for k in range(np_)]
+            levels = [(-1, 0, 2, 6)[k % 4] for k in range(np_)]
+            kids = _children(par)
+            want = ctx.bnb_eval(ctx.make_items([rots[k // 8] for k in range(8 * np_)], kids, [levels[k // 8] for k in range(8 * np_)]))
+            batches.append((ctx.make_items(rots, par, levels), want))
+        # two batches in flight, collected in the order they were submitted, then the slots used again
+        ctx.bnb_submit(0, batches[0][0]); ctx.bnb_submit(1, batches[1][0])
+        got0 = ctx.bnb_collect(0); ctx.bnb_submit(0, batches[2][0])
+        got1 = ctx.bnb_collect(1); got2 = ctx.bnb_collect(0)
+        for got, (_, want) in zip((got0, got1, got2), batches):
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        # a rank's share of a batch, left in a device buffer: zeros for the other parents
+        items, want = batches[0]
+        n = len(items)
+        out = torch.full((16 * n,), -1.0, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.bnb_submit(1, items, first=10, count=20, out_dev=out)
+        assert ctx.bnb_collect(1) is None
+        got = out.cpu().numpy()
+        mask = np.zeros(8 * n, bool); mask[80:240] = True
+        assert np.array_equal(got[:8 * n][mask], want[0][mask]) and np.array_equal(got[8 * n:][mask], want[1][mask])
+        assert not got[:8 * n][~mask].any() and not got[8 * n:][~mask].any()
+        # the same with the copy to the host enqueued afterwards (where several ranks put their sum in between)
+        ctx.bnb_submit(0, items, first=10, count=20, out_dev=out)
+        ctx.sync()
+        out.mul_(2.0)                                           # stands for the collective (on torch's stream, hence the two waits)
+        torch.cuda.synchronize()
+        ctx.bnb_fetch(0, out)
+        ub2, lb2 = ctx.bnb_collect(0)
+        assert np.array_equal(ub2[mask], 2 * want[0][mask]) and np.array_equal(lb2[mask], 2 * want[1][mask]) and not ub2[~mask].any()
+        with pytest.raises(Exception):
+            ctx.bnb_collect(1)                                  # nothing in flight
+    finally:
+        ctx.close()
