@@ -117,6 +117,19 @@ __global__ void k_edt_bricks(const int* __restrict__ sq, int div, int nb, unsign
     out[e] = (unsigned short)v;
 }
 
+// One step of the butterfly over 2 * CNT values per lane: the lanes with bit `o` set keep the upper CNT values and
+// hand the lower ones to their partner l ^ o, the others the other way round; each adds what it receives.
+template <int CNT>
+static __device__ __forceinline__ void bnb_fold(double* v, int lane, int o) {
+    const bool upper = (lane & o) != 0;
+#pragma unroll
+    for (int k = 0; k < CNT; k++) {
+        const double send = upper ? v[k] : v[k + CNT];
+        const double keep = upper ? v[k + CNT] : v[k];
+        v[k] = keep + __shfl_xor(send, o);
+    }
+}
+
 static __device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
 
 // Eight items per workgroup. The eight children of a translation cube (src/GoIcp.cpp:391-401) share the rotation, the
@@ -269,13 +282,23 @@ __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __re
             lb[j] += (double)(dis * dis);
         }
     }
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        for (int o = 32; o > 0; o >>= 1) { ub[j] += __shfl_xor(ub[j], o); lb[j] += __shfl_xor(lb[j], o); }
+    // The sixteen sums of the wave by one butterfly instead of sixteen: at each of the first four steps a lane hands the
+    // half of its values that its partner keeps to the partner and adds what it receives to the half it keeps, so the
+    // pairs added at every step are those of the plain butterfly over lanes l and l ^ o (whose result is the same bits
+    // in every lane, addition being commutative), at a quarter of the instructions.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
+    double v[16];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { sm8[2 * j][wave] = ub[j]; sm8[2 * j + 1][wave] = lb[j]; }
+    for (int j = 0; j < 8; j++) { v[j] = ub[j]; v[8 + j] = lb[j]; }
+    bnb_fold<8>(v, lane, 32);
+    bnb_fold<4>(v, lane, 16);
+    bnb_fold<2>(v, lane, 8);
+    bnb_fold<1>(v, lane, 4);
+    v[0] += __shfl_xor(v[0], 2);
+    v[0] += __shfl_xor(v[0], 1);
+    if ((lane & 3) == 0) {
+        const int which = lane >> 2;                 // 0 .. 7: ub of child `which`, 8 .. 15: lb of child `which - 8`
+        sm8[which < 8 ? 2 * which : 2 * (which - 8) + 1][wave] = v[0];
     }
     __syncthreads();
     if (threadIdx.x < 16) {
