@@ -835,7 +835,7 @@ void GoIcp::collect_parents(int slot, std::vector<float>& ub, std::vector<float>
 
 void GoIcp::run_searches(const std::vector<Search*>& ss) {
     const int width = std::max(1, frontier_width);
-    const int ahead = width == 1 ? std::max(0, lookahead) : 0;
+    const int ahead_base = width == 1 ? std::max(0, lookahead) : 0;
     std::vector<size_t> cand;    // look-ahead: heap positions still to visit
     // Takes the children's bounds of one popped parent in the reference's order (src/GoIcp.cpp:403-452).
     auto take = [&](Search& s, const TransNode& parent, const float* u8, const float* l8) {
@@ -866,6 +866,15 @@ void GoIcp::run_searches(const std::vector<Search*>& ss) {
     auto build = [&](Group& g) {
         Stopwatch w_{g_t_build};
         g.parents.clear();
+        // When only a few searches of the group are still running, a step is a round trip for a handful of cubes: they
+        // look further ahead then (up to 32 cubes each, about 64 parent cubes per batch), which costs little on so
+        // small a batch and saves most of the remaining steps. Looking ahead changes no decision.
+        int ahead = ahead_base;
+        if (ahead_base > 0 && tail_lookahead) {
+            size_t active = 0;
+            for (size_t si = g.lo; si < g.hi; si++) active += !ss[si]->done;
+            if (active > 0 && active * (size_t)(1 + ahead_base) < 64) ahead = std::max(ahead_base, (int)std::min<size_t>(32, 64 / active));
+        }
         for (size_t si = g.lo; si < g.hi; si++) {
             Search& s = *ss[si];
             s.pending.clear();

@@ -324,6 +324,7 @@ public:
     // group's bounds while the other group's batch is evaluated (one GPU, device sums). Decisions are unchanged: a
     // search never looks at another search's state.
     bool pipeline = true;
+    bool tail_lookahead = true;   // the last few running searches of a step look further ahead (fewer, fuller batches; same decisions)
     long long max_rot_pops = 0;   // 0 = unlimited
     Collective comm;              // world > 1: every bound batch is split over the ranks
     // statistics
