@@ -122,8 +122,8 @@ def main():
     ap.add_argument("--nn-points", type=int, default=1_000_000)
     ap.add_argument("--big-points", type=int, default=16_000_000, help="points of the large scan-to-model pair (0 = skip)")
     ap.add_argument("--no-goicp", action="store_true", help="skip the Go-ICP bunny-270 extra")
-    ap.add_argument("--goicp-lookahead", type=int, default=2, help="queued translation cubes whose children are evaluated ahead of time")
-    ap.add_argument("--goicp-speculate", type=int, default=127, help="rotation cubes whose inner searches run ahead of time in the same launches")
+    ap.add_argument("--goicp-lookahead", type=int, default=1, help="queued translation cubes whose children are evaluated ahead of time")
+    ap.add_argument("--goicp-speculate", type=int, default=255, help="rotation cubes whose inner searches run ahead of time in the same launches")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo for CPU-side rehearsal)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()

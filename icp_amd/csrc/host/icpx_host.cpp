@@ -870,7 +870,7 @@ void GoIcp::run_searches(const std::vector<Search*>& ss) {
         // look further ahead then (up to 32 cubes each, about 64 parent cubes per batch), which costs little on so
         // small a batch and saves most of the remaining steps. Looking ahead changes no decision.
         int ahead = ahead_base;
-        if (ahead_base > 0 && tail_lookahead) {
+        if (width == 1 && tail_lookahead) {
             size_t active = 0;
             for (size_t si = g.lo; si < g.hi; si++) active += !ss[si]->done;
             if (active > 0 && active * (size_t)(1 + ahead_base) < 64) ahead = std::max(ahead_base, (int)std::min<size_t>(32, 64 / active));
