@@ -1397,6 +1397,7 @@ int icpxh_goicp_options(void* p, int run_bnb, int batched, int parity_sums, int 
 }
 int icpxh_goicp_exact_residuals(void* p, int on) { ((HGo*)p)->go->exact_residuals = on != 0; return 0; }
 int icpxh_goicp_pipeline(void* p, int on) { ((HGo*)p)->go->pipeline = on != 0; return 0; }
+int icpxh_goicp_tail_lookahead(void* p, int on) { ((HGo*)p)->go->tail_lookahead = on != 0; return 0; }
 // Device-side collective: allreduce_dev sums n doubles at a device address inside [dev_buffer, dev_buffer + capacity) over
 // the ranks, in place, on the stream given here (which the context then uses for everything).
 int icpxh_goicp_set_collective_dev(void* p, int rank, int world, void (*allreduce_dev)(double*, int), double* dev_buffer,

@@ -45,6 +45,7 @@ def _lib():
         lib.icpxh_goicp_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int]
         lib.icpxh_goicp_exact_residuals.argtypes = [C.c_void_p, C.c_int]
         lib.icpxh_goicp_pipeline.argtypes = [C.c_void_p, C.c_int]
+        lib.icpxh_goicp_tail_lookahead.argtypes = [C.c_void_p, C.c_int]
         lib.icpxh_goicp_set_collective_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.icpxh_goicp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
         lib.icpxh_goicp_registration.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -276,10 +277,11 @@ class GoIcp:
             _ck(_lib().icpxh_goicp_set_collective(self._h, rank, world, self._cb))
 
     def options(self, run_bnb=True, batched=True, parity_sums=False, frontier_width=1, max_rot_pops=0, lookahead=4, speculate=0,
-                exact_residuals=False, pipeline=True):
+                exact_residuals=False, pipeline=True, tail_lookahead=True):
         _ck(_lib().icpxh_goicp_options(self._h, int(run_bnb), int(batched), int(parity_sums), frontier_width, max_rot_pops, lookahead, speculate))
         _lib().icpxh_goicp_exact_residuals(self._h, int(exact_residuals))
         _lib().icpxh_goicp_pipeline(self._h, int(pipeline))
+        _lib().icpxh_goicp_tail_lookahead(self._h, int(tail_lookahead))
         return self
 
     def registration(self, want_points=False):

@@ -240,11 +240,15 @@ def test_goicp_bunny270_against_oracle_golden(bunny000, bun270):
     assert abs(rs["lb"] - gold["lb"]) <= 1e-6 * gold["lb"]      # (inner_evals also counts the bounds evaluated ahead of time, so it is not compared)
     # bounds evaluated ahead of time change neither a decision nor the result of the reference's order: the same
     # rotation cubes, bit-identical optimum and lower bound, in fewer launches
-    r1 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=0).registration()
-    r4 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=4).registration()
-    assert r4["rot_pops"] == r1["rot_pops"] and float(r4["optError"]) == float(r1["optError"]) and r4["lb"] == r1["lb"]
-    assert np.array_equal(r4["optMat"], r1["optMat"])
-    assert r4["launches"] < r1["launches"]
+    # (tail_lookahead, the wider look-ahead of the last running searches of a step, would make the two settings alike
+    # here, where a step has only 16 searches; it is compared separately)
+    r1 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=0, tail_lookahead=False).registration()
+    r4 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=4, tail_lookahead=False).registration()
+    rt = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=0).registration()
+    for r in (r4, rt):
+        assert r["rot_pops"] == r1["rot_pops"] and float(r["optError"]) == float(r1["optError"]) and r["lb"] == r1["lb"]
+        assert np.array_equal(r["optMat"], r1["optMat"])
+        assert r["launches"] < r1["launches"]
 
 
 @pytest.mark.parametrize("scale,remain", [(1.0, 100), (100.0, 100), (100.0, 80)])
