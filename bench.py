@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--goicp-speculate", type=int, default=255, help="rotation cubes whose inner searches run ahead of time in the same launches")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo for CPU-side rehearsal)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--extra-limit", type=float, default=420.0,
+                    help="seconds the legs after the headline may take before the line is printed without the rest")
     args = ap.parse_args()
 
     import torch
@@ -203,6 +205,37 @@ def main():
 
     extra = {}
     roofline_nn = None
+    cpu = None
+
+    # The legs below share collectives between the ranks: a rank that fails inside one would leave the others waiting
+    # in theirs. The headline is measured by now, so a watchdog prints the line with what there is when the legs
+    # overrun their limit, and ends the process (every rank has one; exactly one line is printed either way).
+    import threading
+    emit_lock = threading.Lock()
+    emitted = [False]
+
+    def emit(timed_out=False):
+        with emit_lock:
+            if emitted[0]:
+                return
+            emitted[0] = True
+            if timed_out:
+                extra.setdefault("errors", {})["timeout"] = f"legs after the headline exceeded {args.extra_limit} s; line printed without the rest"
+            if rank == 0:
+                line = {"metric": "EDT voxels/s", "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+                        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+                        "vs_baseline": None, "dtype": "int32", "data": "bunny045 scan (40097 points) voxelised on a 300^3 grid",
+                        "config": {"workload": "EDT 300^3 from bunny045 (reference box rule), full build per step",
+                                   "div": DIV, "occupied_voxels": int(info["occupied"]), "parallelism": "replicas only" if world > 1 else "1 GPU"},
+                        "roofline": roofline, "roofline_nn": roofline_nn, "cpu_baseline": cpu, "extra": extra}
+                print(json.dumps(line), flush=True)
+            if timed_out:
+                os._exit(0)
+
+    watchdog = threading.Timer(args.extra_limit, emit, kwargs={"timed_out": True})
+    watchdog.daemon = True
+    watchdog.start()
+
     if not args.no_extra:
         try:
             # DT lookup: bunny000 points against the grid
@@ -366,7 +399,6 @@ def main():
             import traceback; traceback.print_exc()
             extra.setdefault("errors", {})["goicp"] = repr(exc)[:300]
 
-    cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as O
         mn, cell = O.ldt_box(tgt, DIV)
@@ -394,14 +426,8 @@ def main():
             O.icp(load_scan("bunny000"), tgt, 30, nn_mode=0, threads=2)
             cpu["threads2"]["icp_bunny045_30it_ms"] = (time.perf_counter() - t0) * 1e3
 
-    if rank == 0:
-        line = {"metric": "EDT voxels/s", "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "int32", "data": "bunny045 scan (40097 points) voxelised on a 300^3 grid",
-                "config": {"workload": "EDT 300^3 from bunny045 (reference box rule), full build per step",
-                           "div": DIV, "occupied_voxels": int(info["occupied"]), "parallelism": "replicas only" if world > 1 else "1 GPU"},
-                "roofline": roofline, "roofline_nn": roofline_nn, "cpu_baseline": cpu, "extra": extra}
-        print(json.dumps(line), flush=True)
+    watchdog.cancel()
+    emit()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
