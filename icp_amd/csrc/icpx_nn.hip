@@ -173,15 +173,23 @@ __device__ __forceinline__ void scan_cell(const GridView& g, int cell, double qx
 __device__ __forceinline__ void scan_cell(const GridView& g, int cell, double qx, double qy, double qz, const QueryF& f, Best& b) {
     const int first = g.start[cell], last = g.start[cell + 1];
     float thr = f.point_threshold(b.d2);
-    for (int k = first; k < last; k++) {
-        const float4 p = g.pts[k];
-        const float fx = f.x - p.x, fy = f.y - p.y, fz = f.z - p.z;
-        const float sf = (fx * fx + fy * fy) + fz * fz;
-        if (sf > thr) continue;
-        const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
-        const double d = (dx * dx + dy * dy) + dz * dz;
-        b.offer(d, __float_as_int(p.w), k);
-        thr = f.point_threshold(b.d2);
+    // four points per round, their loads issued together (a cell holds about five points: one wait for memory per
+    // round instead of one per point; positions past the end repeat the last point and are not offered)
+    for (int k0 = first; k0 < last; k0 += 4) {
+        float4 p4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p4[u] = g.pts[min(k0 + u, last - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float4 p = p4[u];
+            const float fx = f.x - p.x, fy = f.y - p.y, fz = f.z - p.z;
+            const float sf = (fx * fx + fy * fy) + fz * fz;
+            if (k0 + u >= last || sf > thr) continue;
+            const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+            const double d = (dx * dx + dy * dy) + dz * dz;
+            b.offer(d, __float_as_int(p.w), k0 + u);
+            thr = f.point_threshold(b.d2);
+        }
     }
 }
 
