@@ -709,17 +709,22 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
             const f2 qx2 = {(float)p[0], (float)p[0]}, qy2 = {(float)p[1], (float)p[1]}, qz2 = {(float)p[2], (float)p[2]};
             unsigned u1 = 0x7f800000u, u2 = 0x7f800000u;          // +infinity
             int vlo = 0;                     // first list position of the part of the box u1 was found in
-            const int sub = lane & 7;
             for (int lo = 0; lo < total; lo += TILE_CAP) {
                 const int hi = min(lo + TILE_CAP, total), m = hi - lo;
                 wave_sync();                 // column tables written / the previous part has been compared
-                // eight lanes copy one column at a time (consecutive lanes, consecutive points): its part inside [lo, hi)
-                for (int c = lane >> 3; c < ncols; c += 8) {
-                    const int at = s_pre[c], end = s_pre[c + 1];
-                    if (end <= lo || at >= hi) continue;
-                    const int first = s_first[c];
-                    for (int v = max(at, lo) + sub; v < min(end, hi); v += 8) {
-                        const float4 t = g.pts[first + (v - at)];
+                // a lane per list position: its column (the last one that starts at or before it) by bisection of the prefix
+                // sums, then its point (copying column by column, eight lanes a column, took three times the instructions:
+                // the columns of a box hold one to five of its points each)
+                for (int r0 = 0; lo + r0 < hi; r0 += 64) {
+                    const int v = lo + r0 + lane;
+                    int col = 0;
+#pragma unroll
+                    for (int step = TILE_COLS / 2; step > 0; step >>= 1) {
+                        const int cand = col + step;
+                        if (cand < ncols && s_pre[cand] <= v) col = cand;
+                    }
+                    if (v < hi) {
+                        const float4 t = g.pts[s_first[col] + (v - s_pre[col])];
                         s_x[v - lo] = t.x; s_y[v - lo] = t.y; s_z[v - lo] = t.z; s_w[v - lo] = __int_as_float(v - lo);
                     }
                 }
