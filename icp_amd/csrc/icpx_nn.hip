@@ -486,16 +486,10 @@ constexpr int BALL_MAX_PTS = 4096;       // most points staged for a tile (16 ti
 constexpr float BALL_MIN_REACH = 2.f;    // a query at least this many cells from its candidate counts as far from the surface
 constexpr float BALL_MAX_SPREAD = 12.f;  // most cells from the tile's centre to one of its queries, for the same reason
 
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
+// Minimum / maximum over the lanes of the wave (all of them active), by the device library's cross-lane reduction:
+// register-to-register row operations, where six rounds of __shfl_xor go through the LDS crossbar one after the other.
+__device__ __forceinline__ int wave_min(int v) { return __ockl_wfred_min_i32(v); }
+__device__ __forceinline__ int wave_max(int v) { return __ockl_wfred_max_i32(v); }
 
 // Float threshold above which a candidate's float squared distance proves it strictly farther than `best` (see above).
 __device__ __forceinline__ float prune_threshold(double best, double slack) {
@@ -643,13 +637,16 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         const int ncols = (int)min(ncols_ll, (long long)TILE_COLS + 1);
         // squared distance from the query to the nearest place outside its own block of cells where a target point could be
         // (nothing lies beyond the grid's own faces)
+        // (not needed by a near lane, whose block holds its whole ball: in the converged passes no lane computes it)
         double outside = INFINITY;
-        if (lx0 > 0)        { const double t = fmax(p[0] - (ox + lx0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
-        if (lx1 < g.dx - 1) { const double t = fmax(ox + (lx1 + 1) * h - p[0] - margin, 0.0); outside = fmin(outside, t * t); }
-        if (ly0 > 0)        { const double t = fmax(p[1] - (oy + ly0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
-        if (ly1 < g.dy - 1) { const double t = fmax(oy + (ly1 + 1) * h - p[1] - margin, 0.0); outside = fmin(outside, t * t); }
-        if (lz0 > 0)        { const double t = fmax(p[2] - (oz + lz0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
-        if (lz1 < g.dz - 1) { const double t = fmax(oz + (lz1 + 1) * h - p[2] - margin, 0.0); outside = fmin(outside, t * t); }
+        if (!near_lane) {
+            if (lx0 > 0)        { const double t = fmax(p[0] - (ox + lx0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
+            if (lx1 < g.dx - 1) { const double t = fmax(ox + (lx1 + 1) * h - p[0] - margin, 0.0); outside = fmin(outside, t * t); }
+            if (ly0 > 0)        { const double t = fmax(p[1] - (oy + ly0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
+            if (ly1 < g.dy - 1) { const double t = fmax(oy + (ly1 + 1) * h - p[1] - margin, 0.0); outside = fmin(outside, t * t); }
+            if (lz0 > 0)        { const double t = fmax(p[2] - (oz + lz0 * h) - margin, 0.0); outside = fmin(outside, t * t); }
+            if (lz1 < g.dz - 1) { const double t = fmax(oz + (lz1 + 1) * h - p[2] - margin, 0.0); outside = fmin(outside, t * t); }
+        }
 
         // Stage the box unless that is clearly wasted: when most lanes already hold a candidate (their previous
         // pair) and hardly any of those is near enough for the box to settle the query.
