@@ -214,23 +214,39 @@ def main():
     emit_lock = threading.Lock()
     emitted = [False]
 
+    def snapshot(obj):
+        # the main thread may be adding keys while the watchdog thread copies: try again a few times, then give up on the part
+        import copy
+        for _ in range(20):
+            try:
+                return copy.deepcopy(obj)
+            except RuntimeError:
+                time.sleep(0.01)
+        return {"errors": {"snapshot": "could not copy a dictionary that was being written"}}
+
     def emit(timed_out=False):
         with emit_lock:
             if emitted[0]:
                 return
             emitted[0] = True
-            if timed_out:
-                extra.setdefault("errors", {})["timeout"] = f"legs after the headline exceeded {args.extra_limit} s; line printed without the rest"
-            if rank == 0:
-                line = {"metric": "EDT voxels/s", "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
-                        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-                        "vs_baseline": None, "dtype": "int32", "data": "bunny045 scan (40097 points) voxelised on a 300^3 grid",
-                        "config": {"workload": "EDT 300^3 from bunny045 (reference box rule), full build per step",
-                                   "div": DIV, "occupied_voxels": int(info["occupied"]), "parallelism": "replicas only" if world > 1 else "1 GPU"},
-                        "roofline": roofline, "roofline_nn": roofline_nn, "cpu_baseline": cpu, "extra": extra}
-                print(json.dumps(line), flush=True)
-            if timed_out:
-                os._exit(0)
+            try:
+                ex, cp, rn = snapshot(extra), snapshot(cpu), snapshot(roofline_nn)
+                if timed_out:
+                    ex.setdefault("errors", {})["timeout"] = f"legs after the headline exceeded {args.extra_limit} s; line printed without the rest"
+                if rank == 0:
+                    line = {"metric": "EDT voxels/s", "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+                            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+                            "vs_baseline": None, "dtype": "int32", "data": "bunny045 scan (40097 points) voxelised on a 300^3 grid",
+                            "config": {"workload": "EDT 300^3 from bunny045 (reference box rule), full build per step",
+                                       "div": DIV, "occupied_voxels": int(info["occupied"]), "parallelism": "replicas only" if world > 1 else "1 GPU"},
+                            "roofline": roofline, "roofline_nn": rn, "cpu_baseline": cp, "extra": ex}
+                    print(json.dumps(line), flush=True)
+            finally:
+                if timed_out:
+                    # a leg hung (a rank stuck in a collective, a GPU call that never returns): the headline is out, but the
+                    # run did not finish, and the exit status has to say so
+                    sys.stdout.flush()
+                    os._exit(3)
 
     watchdog = threading.Timer(args.extra_limit, emit, kwargs={"timed_out": True})
     watchdog.daemon = True

@@ -35,6 +35,18 @@ def _ptr(a, dtype, ctx=None):
     return a.ctypes.data_as(C.c_void_p), HOST
 
 
+def _dev(t, ctx):
+    """Raw device pointer of a CUDA tensor of any dtype, ordered like _ptr: work still pending on torch's current stream
+    (the torch.zeros / .cuda() that produced the tensor) is waited for unless the context launches on that very stream."""
+    import torch
+    if not t.is_cuda or not t.is_contiguous():
+        raise TypeError("expected a contiguous CUDA tensor")
+    cur = torch.cuda.current_stream(t.device)
+    if ctx._stream != cur.cuda_stream:
+        cur.synchronize()
+    return C.c_void_p(t.data_ptr())
+
+
 class Context:
     def __init__(self, device=0):
         self._lib = icpx()
@@ -169,6 +181,16 @@ class Context:
         self._ck(self._lib.icpx_edt_rebuild_timed(self._h, reps, sample_every, ms, C.byref(n)))
         return np.array(list(ms), np.float64) / max(n.value, 1)
 
+    def edt_set_timing(self, on=True):
+        self._ck(self._lib.icpx_edt_set_timing(self._h, 1 if on else 0))
+
+    def edt_last_build(self):
+        """(kernel ms by stage of the attempt that produced the grid, attempts) of the last edt_build* call made with timing on."""
+        ms = (C.c_float * 4)()
+        n = C.c_int()
+        self._ck(self._lib.icpx_edt_last_build(self._h, ms, C.byref(n)))
+        return np.array(list(ms), np.float64), n.value
+
     def edt_info(self):
         div = C.c_uint32(); mn = (C.c_float * 3)(); cell = C.c_float(); occ = C.c_uint64(); dr = C.c_uint64()
         self._ck(self._lib.icpx_edt_info(self._h, C.byref(div), mn, C.byref(cell), C.byref(occ), C.byref(dr)))
@@ -230,20 +252,20 @@ class Context:
         [ub..., lb...], zeros for the other items). Only enqueues on the context's stream."""
         n = len(items)
         count = n - first if count is None else count
-        self._ck(self._lib.icpx_bnb_eval_async(self._h, C.cast(items, C.c_void_p), n, first, count, C.c_void_p(out_dev.data_ptr())))
+        self._ck(self._lib.icpx_bnb_eval_async(self._h, C.cast(items, C.c_void_p), n, first, count, _dev(out_dev, self)))
 
     def bnb_submit(self, slot, parents, first=0, count=None, out_dev=None):
         """icpx_bnb_submit: the eight children of every parent cube in `parents` (make_items records), as batch `slot`."""
         n = len(parents)
         count = n - first if count is None else count
         self._ck(self._lib.icpx_bnb_submit(self._h, slot, C.cast(parents, C.c_void_p), n, first, count,
-                                           C.c_void_p(out_dev.data_ptr()) if out_dev is not None else None))
+                                           _dev(out_dev, self) if out_dev is not None else None))
         self._pending = getattr(self, "_pending", {})
         self._pending[slot] = (n, out_dev is None)
 
     def bnb_fetch(self, slot, out_dev):
         """icpx_bnb_fetch: the bounds a batch left in out_dev (summed over the ranks meanwhile) come to the host after all."""
-        self._ck(self._lib.icpx_bnb_fetch(self._h, slot, C.c_void_p(out_dev.data_ptr())))
+        self._ck(self._lib.icpx_bnb_fetch(self._h, slot, _dev(out_dev, self)))
         self._pending[slot] = (self._pending[slot][0], True)
 
     def bnb_collect(self, slot):
@@ -259,7 +281,7 @@ class Context:
     def download(self, dev_tensor, nbytes=None):
         """icpx_download: waits for the context's stream, returns the tensor's bytes as a numpy array of its dtype."""
         out = np.empty(tuple(dev_tensor.shape), {8: np.float64, 4: np.int32}[dev_tensor.element_size()])
-        self._ck(self._lib.icpx_download(self._h, C.c_void_p(dev_tensor.data_ptr()), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        self._ck(self._lib.icpx_download(self._h, _dev(dev_tensor, self), out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
     def edt_grid_ptr(self):
@@ -270,7 +292,7 @@ class Context:
     def bnb_eval_noalloc(self, items_dev, nitems, out_dev):
         """icpx_bnb_eval_noalloc: items_dev a CUDA uint8 tensor holding `nitems` packed icpx_bnb_item records, out_dev a
         CUDA float64 tensor of 2 * nitems ([ub..., lb...]). Only enqueues on the context's stream: sync() before reading."""
-        self._ck(self._lib.icpx_bnb_eval_noalloc(self._h, C.c_void_p(items_dev.data_ptr()), nitems, C.c_void_p(out_dev.data_ptr())))
+        self._ck(self._lib.icpx_bnb_eval_noalloc(self._h, _dev(items_dev, self), nitems, _dev(out_dev, self)))
 
     def goicp_residuals(self, T):
         T = np.ascontiguousarray(T, np.float64).reshape(16)

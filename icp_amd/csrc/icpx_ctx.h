@@ -90,6 +90,10 @@ struct icpx_ctx {
     EnvTune edt_zy{4, 28, 130}, edt_x{4, 28, 130};
     bool edt_tune_fixed = false;   // shapes came from the environment: do not adapt them to the data
     bool edt_overflowed = false;   // a build needed levels beyond the private ones: use the kernels with pool / spill tiers
+    uint32_t edt_shape_div = 0;    // resolution the shapes above were chosen at (0: none yet); another resolution starts afresh
+    bool edt_time_builds = false;  // icpx_edt_set_timing: checked builds carry start / stop events per stage
+    float edt_build_ms[ICPX_EDT_NSTAGES] = {0, 0, 0, 0};   // kernel times of the last checked build's final attempt, by stage
+    int edt_build_attempts_made = 0;                        // attempts the last checked build needed
     DevBuf edt_bits;         // div*div*edt_words uint64 occupancy bits, then two sets of 8 uint64 counters (alternate builds)
     int edt_epoch = 0;       // counter set of the latest build
     DevBuf edt_rowlist;      // [x][chunk][k] 16-byte records of the non-empty rows of every plane (see k_edt_census)

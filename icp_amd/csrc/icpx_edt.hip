@@ -918,22 +918,84 @@ static int edt_prepare(icpx_ctx* ctx, uint32_t div) {
     return ICPX_OK;
 }
 
-// Runs the kernels until a build fits its stack storage (at most twice) and checks that the grid is not empty.
+// The first build at a resolution up to this one is tried with private levels only (EDT_FIRST_CAP of them, the most
+// that keeps three workgroups per CU) and without the deepest-stack report: a surface scan's stacks at 300^3 are 28 / 33
+// levels deep, and such a build then costs what the adapted rebuilds cost (pass x at 300^3: 43 us against 74 us with
+// the pool variant and the report, which 6 000 waves pay for by polling one counter). A cloud whose stacks are deeper
+// raises the overflow flag (the no-pool site step clamps its level and env_finish reports it) and the build is repeated
+// with the pool variant, which is what larger grids start with: their stacks hardly ever fit, and a wasted attempt
+// costs a whole build.
+constexpr uint32_t EDT_FIRST_DIV = 320;
+constexpr int EDT_FIRST_CAP = 33;
+
+// Runs the kernels until a build fits its stack storage (private levels only where that is likely to do, then the
+// pool, then pool and spill buffer) and checks that the grid is not empty.
 static int edt_build_attempts(icpx_ctx* ctx) {
-    for (int attempt = 0; attempt < 2; attempt++) {
-        ICPX_TRY(icpx_edt_run(ctx, true));
+    const EnvTune def{4, 28, 130};
+    if (!ctx->edt_tune_fixed && ctx->edt_shape_div != ctx->div) {
+        ctx->edt_zy = ctx->edt_x = ctx->div <= EDT_FIRST_DIV ? EnvTune{4, EDT_FIRST_CAP, 0} : def;
+        ctx->edt_overflowed = false;
+    }
+    ctx->edt_shape_div = ctx->div;
+    // Private levels only (the first choice above, or what an earlier build's report led to): no report, a deeper
+    // stack shows as an overflow and sends the build to the pool variant
+    const bool optimistic = !ctx->edt_tune_fixed && !ctx->edt_overflowed && ctx->edt_zy.chunks == 0 && ctx->edt_x.chunks == 0;
+    hipEvent_t ev[2 * ICPX_EDT_NSTAGES];
+    if (ctx->edt_time_builds)
+        for (auto& e : ev) ICPX_CHECK_HIP(ctx, hipEventCreate(&e));
+    int rc = ICPX_OK;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const bool first_try = optimistic && attempt == 0;
+        // this attempt runs the kernels that use the spill buffer, and has one of the right size
+        const bool with_spill = ctx->edt_overflowed && ctx->edt_spill.cap >= edt_spill_bytes(ctx);
+        rc = edt_run_impl(ctx, ctx->edt_time_builds ? ev : nullptr, first_try ? 0 : 1);
+        if (rc != ICPX_OK) break;
         u64 counters[8];
-        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(counters, edt_counters(ctx), sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
-        ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (counters[0] == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "EDT build: no target point falls inside the grid");
-        if (!counters[4] && !counters[5]) { edt_adapt(ctx, counters[3], counters[7]); break; }
+        hipError_t he = hipMemcpyAsync(counters, edt_counters(ctx), sizeof counters, hipMemcpyDeviceToHost, ctx->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+        if (he != hipSuccess) { ctx->set_error("EDT build: reading the counters failed: %s", hipGetErrorString(he)); rc = ICPX_EHIP; break; }
+        ctx->edt_build_attempts_made = attempt + 1;
+        if (counters[0] == 0) { ctx->set_error("EDT build: no target point falls inside the grid"); rc = ICPX_EINVAL; break; }
+        if (!counters[4] && !counters[5]) {
+            if (!first_try) edt_adapt(ctx, counters[3], counters[7]);
+            else if (getenv("ICPX_EDT_VERBOSE")) fprintf(stderr, "icpx edt: div %u first build with %d private levels fits\n", ctx->div, EDT_FIRST_CAP);
+            break;
+        }
+        if (first_try) {   // deeper stacks than the private levels: the pool variant, with the report that shapes later builds
+            ctx->edt_zy = ctx->edt_x = def;
+            continue;
+        }
         ctx->edt_overflowed = true;   // from now on the kernels with the pool / spill tiers, until a build fits
         // Some row's envelope did not fit the LDS levels and pool: give the passes a spill buffer and repeat
         // the build.
-        if (attempt == 1) ICPX_FAIL(ctx, ICPX_EHIP, "EDT build: stack overflow persisted with a spill buffer");
-        ICPX_TRY(icpx_reserve(ctx, ctx->edt_spill, edt_spill_bytes(ctx)));
+        if (with_spill || attempt == 2) { ctx->set_error("EDT build: stack overflow persisted with a spill buffer"); rc = ICPX_EHIP; break; }
+        rc = icpx_reserve(ctx, ctx->edt_spill, edt_spill_bytes(ctx));
+        if (rc != ICPX_OK) break;
     }
+    if (ctx->edt_time_builds) {
+        for (int k = 0; k < ICPX_EDT_NSTAGES; k++) {
+            float ms = 0.f;
+            if (rc == ICPX_OK) (void)hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]);
+            ctx->edt_build_ms[k] = ms;
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    if (rc != ICPX_OK) return rc;
     ctx->edt_ready = true;
+    return ICPX_OK;
+}
+
+extern "C" int icpx_edt_set_timing(icpx_ctx* ctx, int on) {
+    if (!ctx) return ICPX_EINVAL;
+    ctx->edt_time_builds = on != 0;
+    return ICPX_OK;
+}
+
+extern "C" int icpx_edt_last_build(icpx_ctx* ctx, float stage_ms[ICPX_EDT_NSTAGES], int* attempts) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_last_build: no EDT has been built");
+    if (stage_ms) for (int k = 0; k < ICPX_EDT_NSTAGES; k++) stage_ms[k] = ctx->edt_build_ms[k];
+    if (attempts) *attempts = ctx->edt_build_attempts_made;
     return ICPX_OK;
 }
 

@@ -49,6 +49,8 @@ ICPX_SYMBOLS = {
     "icpx_edt_lookup_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "icpx_edt_rebuild_async": (C.c_int, [C.c_void_p]),
     "icpx_edt_rebuild_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "icpx_edt_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "icpx_edt_last_build": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "icpx_edt_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "icpx_edt_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "icpx_edt_grid_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

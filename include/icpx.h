@@ -154,6 +154,14 @@ int icpx_edt_rebuild_async(icpx_ctx* ctx);
 #define ICPX_EDT_NSTAGES 4
 int icpx_edt_rebuild_timed(icpx_ctx* ctx, int reps, int sample_every, float stage_ms[ICPX_EDT_NSTAGES], int* sampled);
 
+/* The first build for a target is the one the reference's use pays for (one LDT per target, src/testLDT.cpp:40-212,
+ * timed there with omp_get_wtime, :43 / :209). icpx_edt_set_timing(ctx, 1) makes every later icpx_edt_build* call
+ * carry start / stop HIP events per stage; icpx_edt_last_build then returns the kernel milliseconds by stage of the
+ * attempt that produced the grid, and the number of attempts the build needed (1: the first choice of stack storage
+ * held; more: a pass reported an overflow and the kernels ran again with more storage). Either output may be NULL. */
+int icpx_edt_set_timing(icpx_ctx* ctx, int on);
+int icpx_edt_last_build(icpx_ctx* ctx, float stage_ms[ICPX_EDT_NSTAGES], int* attempts);
+
 /* LDT's public fields (src/testLDT.cpp:31-35): div, _min, cellLen; plus the occupied-voxel count and
  * the number of points dropped by the splat. Any output pointer may be NULL. */
 int icpx_edt_info(icpx_ctx* ctx, uint32_t* div, float min3[3], float* cell_len, uint64_t* occupied, uint64_t* dropped);

@@ -8,6 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# ICPX_ORACLE_SAN=1 loads the AddressSanitizer / UBSan builds (`make -C oracle asan`, tools/run_asan.sh)
+_SAN = os.environ.get("ICPX_ORACLE_SAN", "") not in ("", "0")
 _lib = None
 _ref = None
 
@@ -21,7 +23,7 @@ _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.path.join(_HERE, "_asan", "liboracle.so") if _SAN else os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             raise RuntimeError("oracle/liboracle.so missing: run `make -C oracle` (or __graft_entry__.build())")
         _lib = C.CDLL(path)
@@ -34,7 +36,7 @@ def ref():
     """oracle/_ref/libref.so or None (it only exists where /root/reference was present at build time)."""
     global _ref
     if _ref is None:
-        path = os.path.join(_HERE, "_ref", "libref.so")
+        path = os.path.join(_HERE, "_asan" if _SAN else "_ref", "libref.so")
         if not os.path.exists(path):
             return None
         _ref = C.CDLL(path)

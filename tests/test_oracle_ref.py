@@ -51,7 +51,11 @@ def test_svd_and_kabsch_equal_matrix_svd(ref):
 
 def test_exact_edt_against_dt3d(ref, bunny000, bunny045):
     """src/jly_3ddt.cpp DT3D (300^3 vector-propagation DT, the original Go-ICP lookup): an approximate
-    transform on a different voxelisation; the exact LDT distances agree with it within a few cells."""
+    transform on a different voxelisation; the exact LDT distances agree with it within the two voxelisation errors
+    (each at most sqrt(3)/2 of its cell) for every query. DT3D is compiled with automatic variables preset to a byte
+    pattern (oracle/Makefile): as written it returns a local whose vector was never set and reads it as a site
+    in the next sweep (src/jly_3ddt.cpp:70-72, :126-130), so its output depends on register garbage; g++ -O2 leaves
+    zeros there, which plants a site in the grid's corner and moves a million voxels by up to 207 cells."""
     dt = ref.RefDT3D(bunny045, expand=2.0)
     assert dt.size == 300
     d_ref = dt.distance(bunny000.astype(np.float64))
@@ -60,8 +64,7 @@ def test_exact_edt_against_dt3d(ref, bunny000, bunny045):
     sq = ref.edt_meijster(occ)
     d_mine = ref.ldt_lookup(sq, mn, cell, bunny000)
     cell_ref = 1.0 / dt.scale
-    # (a quantile, not the maximum: DT3D's propagation is approximate and single voxels may be off by more)
-    assert np.quantile(np.abs(d_mine - d_ref), 0.999) < 2.0 * (cell + cell_ref)
+    assert np.abs(d_mine - d_ref).max() < 1.0 * (cell + cell_ref)        # observed: 0.83
     assert abs(np.mean(d_mine) - np.mean(d_ref)) < 0.6 * (cell + cell_ref)
 
 
@@ -110,9 +113,9 @@ def test_dt3d_convention_against_dt3d(ref, bunny000, bunny045):
     for q in (bunny000.astype(np.float64), inside, far):
         mine = ref.dt3d_lookup(sq, box["min"], box["scale"], q); theirs = dt.distance(q)
         cells = np.abs(mine - theirs) * box["scale"]
-        # DT3D propagates nearest-site vectors approximately, so single voxels may be off by more; the convention
-        # (box, rounding, overshoot) is what this compares, and a wrong convention moves every query
-        assert np.quantile(cells, 0.999) < 2.0 and np.median(cells) < 0.05, (cells.max(), int(cells.argmax()))
+        # DT3D propagates nearest-site vectors approximately (observed: at most 0.17 cells off the exact transform on
+        # its own voxelisation); a wrong convention (box, rounding, overshoot) moves every query
+        assert cells.max() < 0.5 and np.median(cells) < 0.05, (cells.max(), int(cells.argmax()))
 
 
 def test_knn_distances_equal_nanoflann_and_k_close(ref, bunny000, bunny045):
