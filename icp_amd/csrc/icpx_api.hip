@@ -85,6 +85,7 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
         long long a = 0, b2 = 0;
         if (v && sscanf(v, "%lld,%lld", &a, &b2) == 2 && a >= 0 && b2 >= 0) { ctx->icp_walk_all_tiles = (size_t)a; ctx->icp_ball_min_tiles = (size_t)b2; }
     }
+    { const char* v = getenv("ICPX_BALL_MANY"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->icp_ball_many = (unsigned)a; }
     // ICPX_BNB_GROUP_MIN: bound batches of at least this many items go through the kernel that takes eight items per
     // workgroup (the tests set 0 and a huge value to compare the two kernels)
     {
@@ -301,6 +302,87 @@ int icpx_morton_sort4(icpx_ctx* ctx, float4* pts, size_t n) {
     ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, pts, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_gather4, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scratch_q.as<float4>(), ctx->sort_vals_b.as<unsigned>(), n, pts);
     return icpx_launch_check(ctx, "k_gather4");
+}
+
+// ---- compact tiles for the ICP pass ------------------------------------------------------------------
+// The ICP pass works on tiles of 64 consecutive source points and stages, per tile, the target points around all 64
+// queries: what a tile costs grows with the square of its extent. 64 consecutive points of a Morton order are not a
+// compact group (the curve fills space, the points lie on a surface, and the curve jumps: on a million surface points
+// the distance from a tile's centre to its farthest point averages 4.8 search cells where 64 points cover a patch of
+// 2.2). So every block of CL_B Morton-consecutive points is cut into tiles by median splits, like the leaves of a
+// balanced k-d tree: the block is sorted along the longest axis of its bounding box and cut in the middle, each half
+// again along its own longest axis, down to runs of 64 (mean extent 2.9 cells, mean square 13 against 41). One
+// workgroup per block; keys and the permutation live in LDS, the sorts of all segments of a level run as one bitonic
+// network. Blocks keep their Morton order, so neighbouring tiles still lie in neighbouring places.
+constexpr int CL_B = 8192, CL_T = 1024;
+
+__global__ __launch_bounds__(CL_T) void k_tile_cluster(const float4* __restrict__ in, size_t n, float4* __restrict__ out) {
+    __shared__ float s_key[CL_B];
+    __shared__ unsigned short s_perm[CL_B];
+    __shared__ float s_box[CL_B / 64][6];
+    __shared__ unsigned char s_axis[CL_B / 128];
+    const size_t base = (size_t)blockIdx.x * CL_B;
+    const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cnt = (int)(n - base < (size_t)CL_B ? n - base : (size_t)CL_B);   // positions beyond hold no point: they sort last at every level
+    for (int i = t; i < CL_B; i += CL_T) s_perm[i] = (unsigned short)i;
+    __syncthreads();
+    for (int seg = CL_B; seg > 64; seg >>= 1) {
+        // bounding boxes of the runs of 64 positions (a wave each), then of the segments
+        for (int c = wave; c < CL_B / 64; c += CL_T / 64) {
+            const int at = s_perm[c * 64 + lane];
+            const bool real = at < cnt;
+            const float4 p = real ? in[base + at] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float lo0 = real ? p.x : 3e38f, lo1 = real ? p.y : 3e38f, lo2 = real ? p.z : 3e38f;
+            float hi0 = real ? p.x : -3e38f, hi1 = real ? p.y : -3e38f, hi2 = real ? p.z : -3e38f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lo0 = fminf(lo0, __shfl_xor(lo0, o)); lo1 = fminf(lo1, __shfl_xor(lo1, o)); lo2 = fminf(lo2, __shfl_xor(lo2, o));
+                hi0 = fmaxf(hi0, __shfl_xor(hi0, o)); hi1 = fmaxf(hi1, __shfl_xor(hi1, o)); hi2 = fmaxf(hi2, __shfl_xor(hi2, o));
+            }
+            if (lane == 0) { s_box[c][0] = lo0; s_box[c][1] = lo1; s_box[c][2] = lo2; s_box[c][3] = hi0; s_box[c][4] = hi1; s_box[c][5] = hi2; }
+        }
+        __syncthreads();
+        const int nseg = CL_B / seg, per = seg / 64;
+        if (t < nseg) {
+            float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+            for (int c = t * per; c < (t + 1) * per; c++)
+                for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], s_box[c][a]); hi[a] = fmaxf(hi[a], s_box[c][3 + a]); }
+            const float e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
+            s_axis[t] = (unsigned char)(e0 >= e1 && e0 >= e2 ? 0 : e1 >= e2 ? 1 : 2);
+        }
+        __syncthreads();
+        for (int i = t; i < CL_B; i += CL_T) {
+            const int at = s_perm[i];
+            float key = 3e38f;
+            if (at < cnt) { const float4 p = in[base + at]; const int a = s_axis[i / seg]; key = a == 0 ? p.x : a == 1 ? p.y : p.z; }
+            s_key[i] = key;
+        }
+        __syncthreads();
+        // every aligned segment sorted ascending by key: one bitonic network over the block, whose last merge (k == seg) runs
+        // in the same direction in every segment
+        for (int k = 2; k <= seg; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int q = t; q < CL_B / 2; q += CL_T) {
+                    const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), p2 = i | j;
+                    const bool asc = k == seg || (i & k) == 0;
+                    const float a = s_key[i], b = s_key[p2];
+                    if ((a > b) == asc && a != b) {
+                        s_key[i] = b; s_key[p2] = a;
+                        const unsigned short u = s_perm[i]; s_perm[i] = s_perm[p2]; s_perm[p2] = u;
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    for (int i = t; i < cnt; i += CL_T) out[base + i] = in[base + s_perm[i]];
+}
+
+// Regroups spatially sorted points (icpx_morton_sort4) into compact tiles of 64; pts is rewritten in place.
+int icpx_cluster_tiles4(icpx_ctx* ctx, float4* pts, size_t n) {
+    ICPX_TRY(icpx_reserve(ctx, ctx->scratch_q, n * sizeof(float4)));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, pts, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_tile_cluster, dim3((unsigned)((n + CL_B - 1) / CL_B)), dim3(CL_T), 0, ctx->stream, ctx->scratch_q.as<float4>(), n, pts);
+    return icpx_launch_check(ctx, "k_tile_cluster");
 }
 
 // ---- target ------------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@ struct icpx_ctx {
     unsigned long long tile_counter_base = 0;   // their common value before the next launch
     size_t icp_walk_all_tiles = 1024;           // source clouds with fewer tiles skip the tile kernel: every point is walked (ICPX_ICP_TILES)
     size_t icp_ball_min_tiles = 2048;           // source clouds with at least this many tiles use the ball kernel for far tiles
+    unsigned icp_ball_many = 8;                 // far tiles per wave of the ball kernel from which the large point / column caps apply (ICPX_BALL_MANY)
     DevBuf walk_queue;       // one ICP pass: the source points left to the pyramid walk, in 64 parts: a counter per part (16 words apart, zero between passes), then the parts' entries
     DevBuf partials;         // per-block partial sums
     DevBuf sums;             // ICPX_NSUMS doubles
@@ -162,6 +163,8 @@ int icpx_launch_check(icpx_ctx* ctx, const char* what);
 int icpx_stage_points4(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, int where, float4* dst);
 // Sorts float4 points (w = original index bits) by a 30-bit Morton code over their own bounding box.
 int icpx_morton_sort4(icpx_ctx* ctx, float4* pts, size_t n);
+// Cuts every block of 8192 consecutive points of such an order into compact runs of 64 (median splits), in place.
+int icpx_cluster_tiles4(icpx_ctx* ctx, float4* pts, size_t n);
 
 // icpx_nn.hip
 int icpx_grid_build(icpx_ctx* ctx);

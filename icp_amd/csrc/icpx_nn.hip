@@ -475,15 +475,25 @@ struct Mat34 { double m[12]; };
 // are left to k_icp_ball or k_icp_walk, which continue from the candidate they hold.
 constexpr int TILE_CAP = 512;            // points staged at a time: 8 KiB of LDS (a power of two: slots are packed into TILE_CAP - 1 bits)
 constexpr int TILE_COLS = 256;           // most columns of a box
-constexpr float TILE_NEAR = 2.0f;        // a lane whose previous pair is nearer than this many cells asks only for the cells that pair bounds
-constexpr int TILE_MAX_PTS = 1536;       // most points of a box: a few times the usual number, so that no tile takes many times as long as the others
+#ifndef ICPX_TILE_NEAR
+#define ICPX_TILE_NEAR 4.0f
+#endif
+constexpr float TILE_NEAR = ICPX_TILE_NEAR;        // a lane whose previous pair is nearer than this many cells asks only for the cells that pair bounds
+                                         // (1 M pair, compact tiles, 30 passes: 20.0 / 18.5 / 17.7 / 17.0 / 17.0 ms for 1.5 / 2 / 3 / 4 / 5 cells here and in BALL_MIN_REACH)
+#ifndef ICPX_TILE_MAX_PTS
+#define ICPX_TILE_MAX_PTS 1536
+#endif
+constexpr int TILE_MAX_PTS = ICPX_TILE_MAX_PTS;       // most points of a box: a few times the usual number, so that no tile takes many times as long as the others
 constexpr int WALK_SHARDS = 64;          // parts of the walk queue and of the far-tile queue (one wave's lanes read the 64 counts)
 constexpr int BALL_MIN_LANES = 8;        // a tile with at least this many open points goes to k_icp_ball, fewer are walked one by one
 constexpr int BALL_MAX_COLS = 16384;     // most cell columns under a tile's ball; beyond that the points are left to the walk
 constexpr int BALL_MAX_PTS = 4096;       // most points staged for a tile (16 times as many when far tiles abound): a wave with a fuller ball ends up as
                                          // the kernel's tail, and its points are cheaper to walk one by one (1 M pair, 30 passes: 25.3 / 23.4 / 22.5 /
                                          // 22.8 / 23.6 ms with 2 048 / 3 072 / 4 096 / 8 192 / 16 384)
-constexpr float BALL_MIN_REACH = 2.f;    // a query at least this many cells from its candidate counts as far from the surface
+#ifndef ICPX_BALL_MIN_REACH
+#define ICPX_BALL_MIN_REACH 4.f
+#endif
+constexpr float BALL_MIN_REACH = ICPX_BALL_MIN_REACH;    // a query at least this many cells from its candidate counts as far from the surface
 constexpr float BALL_MAX_SPREAD = 12.f;  // most cells from the tile's centre to one of its queries, for the same reason
 
 // Minimum / maximum over the lanes of the wave (all of them active), by the device library's cross-lane reduction:
@@ -566,6 +576,7 @@ __device__ __forceinline__ size_t icp_tile_of(int tt, int tiles_per_wave) {
 __device__ unsigned long long g_nn_stats[16];
 __device__ unsigned long long g_ball_t[8];   // wall-clock ticks of k_icp_ball by phase: candidates, geometry, columns, staging, compare, resolve, whole tile
 __device__ unsigned long long g_nn_t0[8192], g_nn_t1[8192];
+__device__ unsigned long long g_ball_t0[8192], g_ball_t1[8192], g_ball_busy[8192], g_ball_n[8192];
 __device__ unsigned g_nn_tile_t[1 << 18], g_nn_tile_steps[1 << 18], g_nn_tile_total[1 << 18];
 #endif
 #ifdef ICPX_NN_STATS
@@ -850,10 +861,13 @@ __device__ __forceinline__ void greedy_candidate(const GridView& g, const unsign
 // and queries whose ball would be too wide or too full go to the walk queue. A tile whose queries lie far apart (the Morton order jumps) is cut into aligned runs of lanes, down to eight, until a run's queries lie together.
 // Work is handed out at run time, like the tiles of k_icp_tile: the list of far tiles (part by part) is cut into eight
 // runs, one per XCD, taken in order through the counters qcount[16 g + 2] (zero before the launch).
+#ifdef ICPX_BALL_WPE
+__attribute__((amdgpu_waves_per_eu(ICPX_BALL_WPE, ICPX_BALL_WPE)))
+#endif
 __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
                                                               int* __restrict__ idx_out, int* __restrict__ seed, const unsigned* __restrict__ far_queue,
                                                               const unsigned long long* __restrict__ far_mask, unsigned* __restrict__ queue,
-                                                              unsigned* __restrict__ qcount, unsigned tiles_per_shard) {
+                                                              unsigned* __restrict__ qcount, unsigned tiles_per_shard, unsigned many_factor) {
     __shared__ float sw_xyz[TILE_WAVES][4][TILE_CAP + 8];
     __shared__ int sw_first[TILE_WAVES][TILE_COLS];
     __shared__ int sw_pre[TILE_WAVES][TILE_COLS + 4];
@@ -867,6 +881,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
     int* const s_first = sw_first[threadIdx.x >> 6];
     int* const s_pre = sw_pre[threadIdx.x >> 6];
     const int lane = (int)(threadIdx.x & 63);
+#ifdef ICPX_NN_STATS
+    if (lane == 0 && icp_wave_id() < 8192) { g_ball_t0[icp_wave_id()] = wall_clock64(); g_ball_busy[icp_wave_id()] = 0; g_ball_n[icp_wave_id()] = 0; }
+#endif
     const unsigned my_count = qcount[lane * 16 + 1];            // lane r: far tiles of part r (WALK_SHARDS == 64)
     const unsigned most = (unsigned)wave_max((int)my_count);
     const unsigned items = most * WALK_SHARDS, group = blockIdx.x & 7u, per_group = (items + 7) / 8;
@@ -875,7 +892,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
     // as the kernel's tail and their points are better walked; with dozens per wave (a cloud of many millions of points far
     // from its target, whose balls hold four times the points of a million-point cloud's) they average out, and the walk
     // would take several times longer for them.
-    const bool many = items >= 8u * gridDim.x * TILE_WAVES;
+    const bool many = items >= many_factor * gridDim.x * TILE_WAVES;
     const int max_pts = many ? 16 * BALL_MAX_PTS : BALL_MAX_PTS, max_cols = many ? 4 * BALL_MAX_COLS : BALL_MAX_COLS;
 
     // (letting a wave whose run is used up go on with the other XCDs' runs moved time between the passes and saved none)
@@ -884,12 +901,21 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
         if (lane == 0) {
             // a look before the addition: additions to one word go one after the other, and with little to do (the converged
             // passes) the kernel would last as long as its waves' additions take
+#ifdef ICPX_BALL_ONE_COUNTER
+            taken = __hip_atomic_load(&qcount[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (taken < items) taken = atomicAdd(&qcount[2], 1u);
+        }
+        taken = __shfl(taken, 0);
+        const unsigned item = taken;
+        if (item >= items) break;       // uniform
+#else
             taken = __hip_atomic_load(&qcount[group * 16 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (taken < per_group) taken = atomicAdd(&qcount[group * 16 + 2], 1u);
         }
         taken = __shfl(taken, 0);
         const unsigned item = group * per_group + taken;
         if (taken >= per_group || item >= items) break;       // uniform
+#endif
         const unsigned shard = item / most, e = item % most;
         if (e >= (unsigned)__shfl((int)my_count, (int)shard)) continue;
         const size_t tile = far_queue[(size_t)shard * tiles_per_shard + e], base = tile * 64;
@@ -1108,6 +1134,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
         const unsigned long long pend = __ballot(mine && !settled);
 #ifdef ICPX_NN_STATS
         if (lane == 0) atomicAdd(&g_ball_t[6], wall_clock64() - t_tile);
+        if (lane == 0 && icp_wave_id() < 8192) { g_ball_busy[icp_wave_id()] += wall_clock64() - t_tile; g_ball_n[icp_wave_id()]++; g_ball_t1[icp_wave_id()] = wall_clock64(); }
         const unsigned long long k_near = __popcll(__ballot(mine && !want));
         if (lane == 0) { atomicAdd(&g_nn_stats[2], 1ull); atomicAdd(&g_nn_stats[3], __popcll(pend) < __popcll(open) ? 1ull : 0ull); atomicAdd(&g_nn_stats[4], (unsigned long long)staged_pts);
                          atomicAdd(&g_nn_stats[5], (unsigned long long)__popcll(pend)); atomicAdd(&g_nn_stats[12], k_near); }
@@ -1486,6 +1513,10 @@ extern "C" int icpx_set_source(icpx_ctx* ctx, const float* xyz, size_t n, size_t
     ICPX_TRY(icpx_reserve(ctx, ctx->src_pts, n * sizeof(float4)));
     ICPX_TRY(icpx_stage_points4(ctx, xyz, n, stride_bytes, where, ctx->src_pts.as<float4>()));
     ICPX_TRY(icpx_morton_sort4(ctx, ctx->src_pts.as<float4>(), n));
+#ifndef ICPX_NO_CLUSTER
+    // clouds that go through the tile kernels: compact tiles (a cloud that is walked point by point gains nothing)
+    if ((n + 63) / 64 >= ctx->icp_walk_all_tiles) ICPX_TRY(icpx_cluster_tiles4(ctx, ctx->src_pts.as<float4>(), n));
+#endif
     // correspondences of the last pass, by sorted position (-1 = none): the next pass starts its search from them
     ICPX_TRY(icpx_reserve(ctx, ctx->nn_seed, n * sizeof(int)));
     ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->nn_seed.p, 0xff, n * sizeof(int), ctx->stream));
@@ -1547,7 +1578,7 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
                        far_queue, far_mask);
     if (use_ball)
         hipLaunchKernelGGL(k_icp_ball, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
-                           ctx->nn_seed.as<int>(), far_queue, far_mask, queue, qcount, tiles_per_shard);
+                           ctx->nn_seed.as<int>(), far_queue, far_mask, queue, qcount, tiles_per_shard, ctx->icp_ball_many);
     const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, (size_t)ctx->num_cus * 8 / WALK_SHARDS) * WALK_SHARDS);
     const unsigned all_blocks = (unsigned)std::min<size_t>((ctx->ns + NN_OCTETS - 1) / NN_OCTETS, (size_t)ctx->num_cus * 8);
     hipLaunchKernelGGL(k_icp_walk, dim3(walk_all ? all_blocks : std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
@@ -1567,6 +1598,18 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
         { unsigned long long bt[8], zz[8] = {0}; hipMemcpyFromSymbol(bt, HIP_SYMBOL(g_ball_t), sizeof bt); hipMemcpyToSymbol(HIP_SYMBOL(g_ball_t), zz, sizeof zz);
           fprintf(stderr, "   BALLT us per far tile: candidates %.1f geometry %.1f columns %.1f staging %.1f compare %.1f resolve %.1f | tile %.1f\n", bt[0] / 100.0 / (h[2] ? h[2] : 1), bt[1] / 100.0 / (h[2] ? h[2] : 1),
                   bt[2] / 100.0 / (h[2] ? h[2] : 1), bt[3] / 100.0 / (h[2] ? h[2] : 1), bt[4] / 100.0 / (h[2] ? h[2] : 1), bt[5] / 100.0 / (h[2] ? h[2] : 1), bt[6] / 100.0 / (h[2] ? h[2] : 1)); }
+        {
+            static std::vector<unsigned long long> b0(8192), b1(8192), bb(8192), bn(8192);
+            hipMemcpyFromSymbol(b0.data(), HIP_SYMBOL(g_ball_t0), 8192 * 8); hipMemcpyFromSymbol(b1.data(), HIP_SYMBOL(g_ball_t1), 8192 * 8);
+            hipMemcpyFromSymbol(bb.data(), HIP_SYMBOL(g_ball_busy), 8192 * 8); hipMemcpyFromSymbol(bn.data(), HIP_SYMBOL(g_ball_n), 8192 * 8);
+            unsigned long long lo = ~0ull, hi = 0; double busy = 0, mxb = 0; unsigned long long ntl = 0, worked = 0, mxn = 0;
+            const int nw = std::min(blocks * TILE_WAVES, 8192);
+            for (int b = 0; b < nw; b++) { lo = std::min(lo, b0[b]); if (bn[b]) { hi = std::max(hi, b1[b]); worked++; } busy += (double)bb[b]; mxb = std::max(mxb, (double)bb[b]); ntl += bn[b]; mxn = std::max(mxn, bn[b]); }
+            std::vector<double> ends; for (int b = 0; b < nw; b++) if (bn[b]) ends.push_back((b1[b] - lo) / 100.0);
+            std::sort(ends.begin(), ends.end());
+            fprintf(stderr, "   BALLW waves %d (%llu got tiles, %llu tiles, most per wave %llu): span %.1f us, busy per wave mean %.1f max %.1f us; wave end times p10 %.1f p50 %.1f p90 %.1f max %.1f\n", nw, worked, ntl, mxn,
+                    hi > lo ? (hi - lo) / 100.0 : 0.0, busy / nw / 100.0, mxb / 100.0, ends.empty() ? 0.0 : ends[ends.size() / 10], ends.empty() ? 0.0 : ends[ends.size() / 2], ends.empty() ? 0.0 : ends[ends.size() * 9 / 10], ends.empty() ? 0.0 : ends.back());
+        }
         unsigned long long z[16] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof z);
         static std::vector<unsigned long long> t0(8192), t1(8192);
