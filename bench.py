@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--no-goicp", action="store_true", help="skip the Go-ICP bunny-270 extra")
     ap.add_argument("--goicp-lookahead", type=int, default=1, help="queued translation cubes whose children are evaluated ahead of time")
     ap.add_argument("--goicp-speculate", type=int, default=255, help="rotation cubes whose inner searches run ahead of time in the same launches")
+    ap.add_argument("--goicp-share-launches", action="store_true", help="several ranks: cut every bound batch into shares (a collective per launch) instead of dealing out the rotation cubes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo for CPU-side rehearsal)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--extra-limit", type=float, default=420.0,
@@ -383,8 +384,10 @@ def main():
             # advance in lock-step, one launch per step (each starts from the optError of the moment the cube is popped,
             # where the reference's one-after-the-other order lets a later search see an earlier one's improvement);
             # `lookahead` and `speculate` only put more cubes into a launch, the decisions are those of lookahead = speculate
-            # = 0. With several ranks every launch is shared: each rank evaluates its share on its GPU, the shares are
-            # summed by one all-reduce of the device buffer (RCCL, same stream), every rank takes the same decisions.
+            # = 0. With several ranks the rotation cubes of a step (the popped one and those searched ahead with it) are
+            # dealt out: each rank runs the inner searches of its cubes on its own GPU without communication, and one
+            # all-reduce per step (RCCL on the context's stream, a few KB) spreads the results; every rank takes the
+            # same decisions. --goicp-share-launches restores the earlier scheme (every launch cut into shares).
             if not args.no_goicp:
                 from icp_amd.host import GoIcp, normalize_goicp
                 gm, gd, _ = normalize_goicp(load_scan("bunny000"), load_scan("bun270"))
@@ -396,7 +399,8 @@ def main():
                         t = torch.from_numpy(a); dist.all_reduce(t)
                     kw = dict(allreduce=allreduce_host)
                 go = GoIcp(gm, gd, mse=1e-3, dt_div=DIV, device=local, rank=rank, world=world, **kw)
-                go.options(batched=True, frontier_width=1, lookahead=args.goicp_lookahead, speculate=args.goicp_speculate)
+                go.options(batched=True, frontier_width=1, lookahead=args.goicp_lookahead, speculate=args.goicp_speculate,
+                           shard_cubes=not args.goicp_share_launches)
                 barrier(); t0 = time.perf_counter()
                 gr = go.registration()
                 barrier()
@@ -408,8 +412,11 @@ def main():
                     "points": int(gd.shape[0]), "order": "inner searches of a rotation cube in lock-step (batched)",
                     "lookahead": args.goicp_lookahead, "speculate": args.goicp_speculate,
                     "searched_ahead_used": gr["spec_hits"], "searched_ahead_discarded": gr["spec_misses"],
-                    "collective": "device all-reduce (RCCL) per launch" if (world > 1 and args.backend == "nccl") else
-                                  ("host all-reduce per launch" if world > 1 else "none")}
+                    "collectives": gr["collectives"],
+                    "collective": "none" if world == 1 else
+                                  (("device all-reduce (RCCL)" if args.backend == "nccl" else "host all-reduce") +
+                                   (" per launch (every batch cut into shares)" if args.goicp_share_launches else
+                                    " per step (rotation cubes dealt out to the ranks)"))}
                 del go
         except Exception as exc:      # an extra leg must not take the headline line with it
             import traceback; traceback.print_exc()

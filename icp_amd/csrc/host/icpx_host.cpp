@@ -673,10 +673,11 @@ void GoIcp::eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub
     inner_evals += (long long)n;
     launches++;
     Stopwatch watch{eval_seconds};
+    const bool shared = shared_launches();
     size_t lo = 0, hi = n;
-    if (comm.world > 1) { lo = n * comm.rank / comm.world; hi = n * (comm.rank + 1) / comm.world; }
+    if (shared) { lo = n * comm.rank / comm.world; hi = n * (comm.rank + 1) / comm.world; }
     std::vector<double> both(2 * n, 0.0);
-    if (comm.world > 1 && comm.allreduce_sum_dev && comm.dev_buffer && comm.dev_capacity >= 16 && !parity_sums) {
+    if (shared && comm.allreduce_sum_dev && comm.dev_buffer && comm.dev_capacity >= 16 && !parity_sums) {
         // Device side: every rank evaluates its share of the batch into the same layout (zeros elsewhere), the sum over
         // the ranks runs on the GPUs on the context's stream, and one copy brings all bounds to the host.
         const size_t cap = comm.dev_capacity / 2;
@@ -685,6 +686,7 @@ void GoIcp::eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub
             const size_t a = m * comm.rank / comm.world, b = m * (comm.rank + 1) / comm.world;
             dev->check(icpx_bnb_eval_async(dev->ctx(), items.data() + c0, m, a, b - a, comm.dev_buffer));
             comm.allreduce_sum_dev(comm.dev_buffer, (int)(2 * m), comm.user);
+            collectives++;
             std::vector<double> part(2 * m);
             dev->check(icpx_download(dev->ctx(), comm.dev_buffer, part.data(), 2 * m * sizeof(double)));
             for (size_t k = 0; k < m; k++) { ub[c0 + k] = (float)part[k]; lb[c0 + k] = (float)part[m + k]; }
@@ -709,9 +711,10 @@ void GoIcp::eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub
             dev->check(icpx_bnb_eval(dev->ctx(), items.data() + lo, m, both.data() + lo, both.data() + n + lo, nullptr));
         }
     }
-    if (comm.world > 1) {
+    if (shared) {
         if (!comm.allreduce_sum_host) throw IcpxFailure(ICPX_EINVAL, "Collective without allreduce_sum_host");
         comm.allreduce_sum_host(both.data(), (int)(2 * n), comm.user);
+        collectives++;
     }
     for (size_t k = 0; k < n; k++) { ub[k] = (float)both[k]; lb[k] = (float)both[n + k]; }
 }
@@ -772,8 +775,9 @@ void GoIcp::submit_parents(int slot, const std::vector<icpx_bnb_item>& parents) 
     Stopwatch watch{eval_seconds};
     slot_count[slot] = n;
     slot_async[slot] = false;
-    const bool dev_collective = comm.world > 1 && comm.allreduce_sum_dev && comm.dev_buffer && comm.dev_capacity >= 64;
-    if (parity_sums || (comm.world > 1 && !dev_collective)) {
+    const bool shared = shared_launches();
+    const bool dev_collective = shared && comm.allreduce_sum_dev && comm.dev_buffer && comm.dev_capacity >= 64;
+    if (parity_sums || (shared && !dev_collective)) {
         std::vector<icpx_bnb_item> items;
         items.reserve(8 * n);
         for (const icpx_bnb_item& p : parents) {
@@ -789,7 +793,7 @@ void GoIcp::submit_parents(int slot, const std::vector<icpx_bnb_item>& parents) 
         eval_items(items, slot_ub[slot], slot_lb[slot]);
         return;
     }
-    if (comm.world > 1) {
+    if (shared) {
         // every rank evaluates its share of the parents into the same layout (zeros elsewhere), the sum over the ranks
         // runs on the GPUs on the context's stream, and one copy brings all bounds to the host. Each slot has its half
         // of the caller's device buffer; a batch that fits it stays in flight (the copy is only enqueued here), a
@@ -800,6 +804,7 @@ void GoIcp::submit_parents(int slot, const std::vector<icpx_bnb_item>& parents) 
         if (16 * n <= half) {
             dev->check(icpx_bnb_submit(dev->ctx(), slot, parents.data(), n, a, b - a, buf));
             comm.allreduce_sum_dev(buf, (int)(16 * n), comm.user);
+            collectives++;
             dev->check(icpx_bnb_fetch(dev->ctx(), slot, buf));
             slot_async[slot] = true;
             return;
@@ -812,6 +817,7 @@ void GoIcp::submit_parents(int slot, const std::vector<icpx_bnb_item>& parents) 
             const size_t a2 = m * comm.rank / comm.world, b2 = m * (comm.rank + 1) / comm.world;
             dev->check(icpx_bnb_submit(dev->ctx(), slot, parents.data() + c0, m, a2, b2 - a2, buf));
             comm.allreduce_sum_dev(buf, (int)(16 * m), comm.user);
+            collectives++;
             part.resize(16 * m);
             dev->check(icpx_download(dev->ctx(), buf, part.data(), 16 * m * sizeof(double)));
             dev->check(icpx_bnb_collect(dev->ctx(), slot, nullptr, nullptr));
@@ -819,8 +825,37 @@ void GoIcp::submit_parents(int slot, const std::vector<icpx_bnb_item>& parents) 
         }
         return;
     }
+    // one submission holds at most 131070 parent cubes (icpx_bnb_submit): a larger batch goes in pieces, each waited for
+    const size_t cap = 131070;
+    if (n > cap) {
+        slot_ub[slot].assign(8 * n, 0.f); slot_lb[slot].assign(8 * n, 0.f);
+        std::vector<double> part;
+        for (size_t c0 = 0; c0 < n; c0 += cap) {
+            const size_t m = std::min(cap, n - c0);
+            dev->check(icpx_bnb_submit(dev->ctx(), slot, parents.data() + c0, m, 0, m, nullptr));
+            part.resize(16 * m);
+            dev->check(icpx_bnb_collect(dev->ctx(), slot, part.data(), part.data() + 8 * m));
+            for (size_t k = 0; k < 8 * m; k++) { slot_ub[slot][8 * c0 + k] = (float)part[k]; slot_lb[slot][8 * c0 + k] = (float)part[8 * m + k]; }
+        }
+        return;
+    }
     dev->check(icpx_bnb_submit(dev->ctx(), slot, parents.data(), n, 0, n, nullptr));
     slot_async[slot] = true;
+}
+
+// In-place sum of host doubles over the ranks: the caller's host collective, or its device collective through the
+// device buffer it provided (upload, sum on the context's stream, download), in pieces if the buffer is smaller.
+void GoIcp::sum_over_ranks(std::vector<double>& v) {
+    if (comm.world <= 1 || v.empty()) return;
+    collectives++;
+    if (comm.allreduce_sum_host) { comm.allreduce_sum_host(v.data(), (int)v.size(), comm.user); return; }
+    if (!(comm.allreduce_sum_dev && comm.dev_buffer && comm.dev_capacity > 0)) throw IcpxFailure(ICPX_EINVAL, "Collective with neither a host nor a device all-reduce");
+    for (size_t c0 = 0; c0 < v.size(); c0 += comm.dev_capacity) {
+        const size_t m = std::min(comm.dev_capacity, v.size() - c0);
+        dev->check(icpx_upload(dev->ctx(), comm.dev_buffer, v.data() + c0, m * sizeof(double)));
+        comm.allreduce_sum_dev(comm.dev_buffer, (int)m, comm.user);
+        dev->check(icpx_download(dev->ctx(), comm.dev_buffer, v.data() + c0, m * sizeof(double)));
+    }
 }
 
 void GoIcp::collect_parents(int slot, std::vector<float>& ub, std::vector<float>& lb) {
@@ -853,7 +888,7 @@ void GoIcp::run_searches(const std::vector<Search*>& ss) {
     // the GPU evaluates one group's batch (and, with several ranks, sums it over the ranks) the host digests the other's
     // bounds and puts its next batch together. With a host-side collective or sequential float sums a batch is evaluated
     // where it is submitted and one group does.
-    const bool host_collective = comm.world > 1 && !(comm.allreduce_sum_dev && comm.dev_buffer && comm.dev_capacity >= 64);
+    const bool host_collective = shared_launches() && !(comm.allreduce_sum_dev && comm.dev_buffer && comm.dev_capacity >= 64);
     const int ngroups = (pipeline && !host_collective && !parity_sums && ss.size() >= 2) ? 2 : 1;
     struct Group { size_t lo, hi; std::vector<icpx_bnb_item> parents; bool in_flight = false; };
     Group groups[2];
@@ -981,7 +1016,7 @@ static bool rotation_of(float v1, float v2, float v3, float R[9]) {
 }
 
 float GoIcp::OuterBnB() {
-    rot_pops = inner_evals = launches = 0;
+    rot_pops = inner_evals = launches = collectives = 0;
     eval_seconds = 0;
 
     // initial error: identity pose, sequential float sum (src/GoIcp.cpp:159-172)
@@ -1069,10 +1104,12 @@ float GoIcp::OuterBnB() {
                     break;
                 }
             std::vector<Search*> run;
+            std::vector<Work*> fresh;     // the cubes whose searches run in this step, in a fixed order (every rank forms the same list)
             if (!cur) {
                 cur.reset(new Work);
                 prepare(parent, *cur);
                 for (Search& s : cur->ss) run.push_back(&s);
+                fresh.push_back(cur.get());
             }
             // With them, in the same launches, the cubes most likely to be popped next: the best of the queue as it
             // stands. Only when a search has to run anyway: a cube found searched already costs no launch at all.
@@ -1095,9 +1132,43 @@ float GoIcp::OuterBnB() {
                     ahead_of_time.emplace_back(new Work);
                     prepare(h[i], *ahead_of_time.back());
                     for (Search& s : ahead_of_time.back()->ss) run.push_back(&s);
+                    fresh.push_back(ahead_of_time.back().get());
                 }
             }
-            if (!run.empty()) run_searches(run);
+            if (!run.empty() && comm.world > 1 && shard_cubes) {
+                // Several ranks: cube i of the step belongs to rank i mod world, which runs its searches to the end on its own
+                // GPU; then one sum over the ranks of a buffer with six slots per search (best error, whether a best cube was
+                // found, that cube), zero in every slot a rank does not own: floats widened to double, added to zeros, exact.
+                std::vector<Search*> mine;
+                for (size_t i = 0; i < fresh.size(); i++)
+                    if ((int)(i % (size_t)comm.world) == comm.rank)
+                        for (Search& s : fresh[i]->ss) mine.push_back(&s);
+                if (!mine.empty()) run_searches(mine);
+                std::vector<double> buf(6 * run.size(), 0.0);
+                size_t pos = 0;
+                for (size_t i = 0; i < fresh.size(); i++)
+                    for (Search& s : fresh[i]->ss) {
+                        if ((int)(i % (size_t)comm.world) == comm.rank) {
+                            double* b = &buf[6 * pos];
+                            b[0] = s.optErrorT; b[1] = s.have_best ? 1.0 : 0.0;
+                            if (s.have_best) { b[2] = s.best.x; b[3] = s.best.y; b[4] = s.best.z; b[5] = s.best.w; }
+                        }
+                        pos++;
+                    }
+                sum_over_ranks(buf);
+                pos = 0;
+                for (size_t i = 0; i < fresh.size(); i++)
+                    for (Search& s : fresh[i]->ss) {
+                        if ((int)(i % (size_t)comm.world) != comm.rank) {
+                            const double* b = &buf[6 * pos];
+                            s.optErrorT = (float)b[0]; s.have_best = b[1] != 0.0;
+                            s.best.x = (float)b[2]; s.best.y = (float)b[3]; s.best.z = (float)b[4]; s.best.w = (float)b[5];
+                            s.best.lb = s.best.ub = 0;
+                            s.done = true;
+                        }
+                        pos++;
+                    }
+            } else if (!run.empty()) run_searches(run);
         } else {
             cur.reset(new Work);
             prepare(parent, *cur);
@@ -1147,6 +1218,11 @@ float GoIcp::OuterBnB() {
         if (finished) break;
     }
     spec_misses += (long long)ahead_of_time.size();
+    if (comm.world > 1 && shard_cubes && batched) {   // bound evaluations and launches of the whole job, not of this rank's share
+        std::vector<double> tot{(double)inner_evals, (double)launches};
+        sum_over_ranks(tot);
+        inner_evals = (long long)tot[0]; launches = (long long)tot[1];
+    }
     if (std::getenv("ICPX_GOICP_VERBOSE"))
         std::fprintf(stderr, "GoIcp: %lld launches, %lld bound evaluations, %.3f s inside the batches; build %.3f take %.3f icp %.3f\n", launches, inner_evals, eval_seconds, g_t_build, g_t_take, g_t_icp), g_t_build = g_t_take = g_t_icp = 0;
     return optError;
@@ -1396,6 +1472,7 @@ int icpxh_goicp_options(void* p, int run_bnb, int batched, int parity_sums, int 
     return 0;
 }
 int icpxh_goicp_exact_residuals(void* p, int on) { ((HGo*)p)->go->exact_residuals = on != 0; return 0; }
+int icpxh_goicp_shard_cubes(void* p, int on) { ((HGo*)p)->go->shard_cubes = on != 0; return 0; }
 int icpxh_goicp_pipeline(void* p, int on) { ((HGo*)p)->go->pipeline = on != 0; return 0; }
 int icpxh_goicp_tail_lookahead(void* p, int on) { ((HGo*)p)->go->tail_lookahead = on != 0; return 0; }
 // Device-side collective: allreduce_dev sums n doubles at a device address inside [dev_buffer, dev_buffer + capacity) over
@@ -1418,7 +1495,7 @@ int icpxh_goicp_set_collective(void* p, int rank, int world, void (*allreduce)(d
     h->go->comm.allreduce_sum_host = &HCollective::tramp;
     return 0;
 }
-// stats: optError, initError, icpError, rot_pops, inner_evals, final_lb, launches, sseThresh, spec_hits, spec_misses
+// stats: optError, initError, icpError, rot_pops, inner_evals, final_lb, launches, sseThresh, spec_hits, spec_misses, collectives
 int icpxh_goicp_registration(void* p, double* optMat16, double* stats8, double* resN3) {
     return guard([&] {
         HGo* h = (HGo*)p;
@@ -1427,7 +1504,7 @@ int icpxh_goicp_registration(void* p, double* optMat16, double* stats8, double* 
         stats8[0] = h->go->optError; stats8[1] = h->go->initError; stats8[2] = h->go->icpError;
         stats8[3] = (double)h->go->rot_pops; stats8[4] = (double)h->go->inner_evals; stats8[5] = h->go->final_lb;
         stats8[6] = (double)h->go->launches; stats8[7] = h->go->sseThresh;
-        stats8[8] = (double)h->go->spec_hits; stats8[9] = (double)h->go->spec_misses;
+        stats8[8] = (double)h->go->spec_hits; stats8[9] = (double)h->go->spec_misses; stats8[10] = (double)h->go->collectives;
         if (resN3) std::memcpy(resN3, r.resN3.data.data(), r.resN3.data.size() * sizeof(double));
     });
 }

@@ -326,7 +326,15 @@ public:
     bool pipeline = true;
     bool tail_lookahead = true;   // the last few running searches of a step look further ahead (fewer, fuller batches; same decisions)
     long long max_rot_pops = 0;   // 0 = unlimited
-    Collective comm;              // world > 1: every bound batch is split over the ranks
+    // world > 1, batched mode. true (default): the rotation cubes of a step (the popped one and the `speculate` searched
+    // ahead with it) are dealt out to the ranks; each rank runs the complete inner searches of its cubes on its own GPU
+    // without any communication, and ONE sum over the ranks (of a buffer in which every rank fills only the slots of
+    // its own searches: best error, best cube) ends the step. A search depends on its cube and the starting error alone,
+    // so every decision is that of one rank. false: every bound batch is cut into shares instead, one collective per
+    // launch (what the first rounds did; kept for comparison).
+    bool shard_cubes = true;
+    Collective comm;              // world > 1: see shard_cubes
+    long long collectives = 0;    // sums over the ranks that the last OuterBnB asked for
     // statistics
     long long rot_pops = 0, inner_evals = 0, launches = 0;
     double eval_seconds = 0;      // wall time spent inside the bound batches (launch, collective, copy back) of the last OuterBnB
@@ -343,6 +351,8 @@ private:
     void run_searches(const std::vector<Search*>& ss);
     void submit_parents(int slot, const std::vector<icpx_bnb_item>& parents);
     void collect_parents(int slot, std::vector<float>& ub, std::vector<float>& lb);
+    bool shared_launches() const { return comm.world > 1 && !(shard_cubes && batched); }   // every launch cut into shares
+    void sum_over_ranks(std::vector<double>& v);
     std::vector<float> slot_ub[2], slot_lb[2];   // bounds of a batch that was evaluated where it was submitted
     std::vector<double> slot_d;
     size_t slot_count[2] = {0, 0};

@@ -652,6 +652,18 @@ extern "C" int icpx_download(icpx_ctx* ctx, const void* dev, void* host, size_t 
     return ICPX_OK;
 }
 
+extern "C" int icpx_upload(icpx_ctx* ctx, void* dev, const void* host, size_t bytes) {
+    if (!ctx) return ICPX_EINVAL;
+    if (bytes == 0) return ICPX_OK;
+    if (!dev || !host) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_upload: NULL pointer");
+    ICPX_TRY(icpx_bind(ctx));
+    ICPX_TRY(bnb_pin_reserve(ctx, bytes));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // an earlier transfer may still be reading the staging area
+    std::memcpy(ctx->bnb_pin, host, bytes);
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(dev, ctx->bnb_pin, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ICPX_OK;
+}
+
 extern "C" int icpx_bnb_eval_noalloc(icpx_ctx* ctx, const icpx_bnb_item* items_dev, size_t nitems, double* out_dev) {
     if (!ctx) return ICPX_EINVAL;
     if (nitems == 0) return ICPX_OK;

@@ -63,6 +63,7 @@ ICPX_SYMBOLS = {
     "icpx_bnb_collect": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "icpx_bnb_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "icpx_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "icpx_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "icpx_bnb_eval_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "icpx_goicp_residuals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
 }

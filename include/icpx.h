@@ -236,6 +236,11 @@ int icpx_bnb_fetch(icpx_ctx* ctx, int slot, const double* out_dev);
 /* Waits for the context's stream and copies `bytes` of device memory to host memory (results of the _async entry
  * points that the caller left in its own device buffers). No counterpart in the reference. */
 int icpx_download(icpx_ctx* ctx, const void* dev, void* host, size_t bytes);
+/* The other way: `bytes` from host memory to a device address, enqueued on the context's stream (through the context's
+ * pinned staging area; the host buffer may be reused as soon as the call returns). The host classes use the pair for
+ * the small result buffers they hand to a caller's device collective (GoIcp's per-step sum over the ranks; the reference
+ * is a single process and has no counterpart, src/GoIcp.cpp:203-344 is the loop whose cubes are dealt out). */
+int icpx_upload(icpx_ctx* ctx, void* dev, const void* host, size_t bytes);
 
 /* No counterpart in the reference. For callers that cannot allocate device memory while they run (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc): the same bounds as icpx_bnb_eval_async

@@ -89,10 +89,11 @@ def allreduce_dev(t):
     # side: shares evaluated on the device, a device buffer handed to the collective, one download afterwards.
     h = t.cpu(); dist.all_reduce(h); t.copy_(h)
 go = GoIcp(m, d, mse=1e-3, dt_div=300, device=0, rank=rank, world=world, allreduce_dev=allreduce_dev, dev_buffer=buf)
-go.options(batched=True, lookahead=4, speculate=int(sys.argv[3]))
+go.options(batched=True, lookahead=4, speculate=int(sys.argv[3]), shard_cubes=sys.argv[4] == "cubes")
 r = go.registration()
 out = dict(optError=float(r["optError"]), lb=float(r["lb"]), rot_pops=r["rot_pops"], optMat=r["optMat"].tolist(), launches=r["launches"],
-           collectives=calls[0], initError=float(r["initError"]), icpError=float(r["icpError"]))
+           collectives=calls[0], counted=r["collectives"], initError=float(r["initError"]), icpError=float(r["icpError"]),
+           spec_hits=r["spec_hits"], inner_evals=r["inner_evals"])
 json.dump(out, open(sys.argv[2] + f".{rank}", "w"))
 dist.barrier(); dist.destroy_process_group()
 """
@@ -120,11 +121,43 @@ def test_goicp_two_ranks_share_every_batch_on_the_device(tmp_path, bunny000, bun
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = str(tmp_path / "res.json")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", port, str(script), ROOT, out, str(speculate)], env=env, capture_output=True, text=True, timeout=300)
+                        "--master-port", port, str(script), ROOT, out, str(speculate), "launches"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = [json.load(open(out + f".{k}")) for k in range(2)]
     for x in res:
         assert x["optError"] == float(one["optError"]) and x["lb"] == float(one["lb"]) and x["rot_pops"] == one["rot_pops"]
         assert np.array_equal(np.array(x["optMat"]), one["optMat"])
         assert x["launches"] == piped["launches"] and x["collectives"] >= x["launches"]   # the ranks advance in two groups too
+    assert res[0] == res[1]
+
+
+@pytest.mark.parametrize("speculate", [3, 127])
+def test_goicp_two_ranks_deal_out_the_rotation_cubes(tmp_path, bunny000, bun270, speculate):
+    """Two processes on cuda:0: the rotation cubes of every step (the popped one and those searched ahead with it) are dealt
+    out to the ranks, each rank runs its cubes' inner searches to the end on its own without communication, and one sum
+    over the ranks per step spreads the results (src/GoIcp.cpp:203-344 is the loop whose cubes are shared out). Same
+    cubes popped, bit-identical optimum, bound and pose as one rank; with 127 cubes searched ahead a collective per 32
+    popped cubes at most, where sharing every launch needs one per launch."""
+    from icp_amd.host import GoIcp
+    m, d = _pair(bunny000, bun270, 8)
+    one = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, lookahead=4, speculate=speculate).registration()
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK)
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = str(tmp_path / "res.json")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, str(script), ROOT, out, str(speculate), "cubes"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = [json.load(open(out + f".{k}")) for k in range(2)]
+    for x in res:
+        assert x["optError"] == float(one["optError"]) and x["lb"] == float(one["lb"]) and x["rot_pops"] == one["rot_pops"]
+        assert np.array_equal(np.array(x["optMat"]), one["optMat"]) and x["spec_hits"] == one["spec_hits"]
+        assert x["collectives"] == x["counted"]                     # every sum over the ranks went through the caller's collective
+        assert x["collectives"] <= one["rot_pops"] - one["spec_hits"] + 1     # one per step that had a search to run, and the closing one
+        if speculate == 127:
+            assert x["collectives"] <= one["rot_pops"] // 32
     assert res[0] == res[1]

@@ -1,5 +1,5 @@
 """One rank of a Go-ICP run whose bound batches are shared by the ranks on the device (rehearsal / debugging).
-usage: torchrun ... tools/goicp_rank.py <repo root> <output prefix> <speculate>"""
+usage: torchrun ... tools/goicp_rank.py <repo root> <output prefix> <speculate> [cubes|launches]"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
@@ -20,7 +20,7 @@ def allreduce_dev(t):
     # side: shares evaluated on the device, a device buffer handed to the collective, one download afterwards.
     h = t.cpu(); dist.all_reduce(h); t.copy_(h)
 go = GoIcp(m, d, mse=1e-3, dt_div=300, device=0, rank=rank, world=world, allreduce_dev=allreduce_dev, dev_buffer=buf)
-go.options(batched=True, lookahead=4, speculate=int(sys.argv[3]))
+go.options(batched=True, lookahead=4, speculate=int(sys.argv[3]), shard_cubes=len(sys.argv) < 5 or sys.argv[4] == "cubes")
 r = go.registration()
 out = dict(optError=float(r["optError"]), lb=float(r["lb"]), rot_pops=r["rot_pops"], optMat=r["optMat"].tolist(), launches=r["launches"],
            collectives=calls[0], initError=float(r["initError"]), icpError=float(r["icpError"]))
