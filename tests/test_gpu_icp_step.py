@@ -175,3 +175,33 @@ def test_icp_step_bunny_pair_every_path(oracle, bunny000, bunny045, monkeypatch,
             np.testing.assert_allclose(sums, ref, rtol=1e-12, atol=1e-12)
     finally:
         ctx.close()
+
+
+def test_icp_million_by_million_30_iterations_against_the_kd_tree_trajectory():
+    """The synthetic 1 M x 1 M pair from start to end: 30 iterations of the host class against the trajectory of the
+    CPU restatement of the reference's loop with its kd-tree (src/SingleThreadIcp.cpp:293-327, src/kdtree.cpp:107-150;
+    tools/make_icp1m_golden.py wrote tests/golden/icp_1m_30it.json). The reference breaks exact ties by traversal
+    order and this library by lowest index, so the pairs may differ at ties; rotation and translation must agree
+    within 1e-5 after every iteration and at the end (observed: 1e-12)."""
+    import hashlib, json, os, sys
+    from conftest import GOLDEN, ROOT
+    sys.path.insert(0, ROOT)
+    from bench import synth_surface, rigid
+    from icp_amd.host import SingleThreadIcp
+    g = json.load(open(os.path.join(GOLDEN, "icp_1m_30it.json")))
+    n = g["points"]
+    tgt = synth_surface(n, 42)
+    Tm = rigid([1, 1, 1], 10.0, [0.02, -0.01, 0.015])
+    src = (synth_surface(n, 43, noise=1e-3).astype(np.float64) @ Tm[:3, :3].T + Tm[:3, 3]).astype(np.float32)
+    if hashlib.sha256(src.tobytes()).hexdigest() != g["src_sha256"] or hashlib.sha256(tgt.tobytes()).hexdigest() != g["tgt_sha256"]:
+        pytest.skip("this numpy draws another synthetic cloud than the one the fixture was made from")
+    r = SingleThreadIcp(src, tgt, iters=30).registration()
+    acc = np.eye(4)
+    worst = 0.0
+    for k in range(30):
+        acc = r["per_iter_T"][k] @ acc
+        worst = max(worst, float(np.abs(acc - np.array(g["T_after_iteration"][k])).max()))
+    assert worst < 1e-5, worst
+    assert np.abs(r["T"] - np.array(g["T"])).max() < 1e-5
+    np.testing.assert_allclose(r["mse"], np.array(g["mse_logged"]), rtol=1e-5)      # the residual logged after every update (float terms in the reference)
+    print("largest deviation from the kd-tree trajectory:", worst)
