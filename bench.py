@@ -102,6 +102,21 @@ def measured_nn_traffic():
         return None
 
 
+def measured_nn_valu_issue():
+    """Vector instructions issued x 4 cycles over the cycles of all 1 024 SIMDs, summed over the kernels of one ICP pass of the
+    1 M x 1 M pair (first pass, converged pass), from the newest counter summary under profiles/ (SQ_INSTS_VALU and
+    GRBM_GUI_ACTIVE, the latter summed over the 8 XCDs); None where the summary lacks the counters. Offline evidence."""
+    data = _newest_profile("r*_icp_pmc.json")
+    out = {}
+    for which in ("first_pass", "converged_pass"):
+        try:
+            ks = data[which].values()
+            out[which] = sum(c["SQ_INSTS_VALU"] for c in ks) * 4.0 / 1024.0 / sum(c["GRBM_GUI_ACTIVE"] / 8.0 for c in ks)
+        except Exception:
+            out[which] = None
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -197,15 +212,39 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_edt_pass_x", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic("k_edt_pass_x"),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_stage[dom], "samples": roofline_samples,
-                "whole_build": {"algorithmic_bytes": 24.0 * voxels, "GB/s": 24.0 * voxels / (ms_per_step * 1e-3) / 1e9,
+                # The whole step priced with the bytes this design moves by construction: the occupancy bits in (1/8 B per
+                # voxel), the in-plane distances out of pass zy (4 B) and through pass x (4 B in, 4 B out). An upper bound on
+                # what it moves in fact: planes and rows without voxels are skipped (compare measured_traffic_bytes).
+                "whole_build": {"algorithmic_bytes": 12.125 * voxels, "GB/s": 12.125 * voxels / (ms_per_step * 1e-3) / 1e9,
+                                "frac": 12.125 * voxels / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "kernel_ms_sum": sum(per_stage.values()),
-                                "measured_traffic_bytes": sum(filter(None, (measured_traffic(k) for k in ("k_edt_splat", "k_edt_census", "k_edt_pass_zy", "k_edt_pass_x")))) or None,
-                                "note": "24 B/voxel counts every plane and row; the passes skip the empty ones, so this rate can exceed what HBM "
-                                        "moves (compare measured_traffic_bytes). It is no roofline fraction; the dominant kernel's is above."},
+                                "measured_traffic_bytes": sum(filter(None, (measured_traffic(k) for k in ("k_edt_splat", "k_edt_census", "k_edt_pass_zy", "k_edt_pass_x")))) or None},
                 "stage_ms": per_stage}
+
+    # The first build for a target is the one the reference's use pays for (one LDT per target, src/testLDT.cpp:40-212):
+    # a fresh context, the target cloud handed over again, one checked build with start / stop events on every kernel.
+    try:
+        cold = []
+        for _ in range(3):
+            c0 = Context(local)
+            c0.set_target(tgt_dev)
+            c0.edt_set_timing(True)
+            t0 = time.perf_counter(); c0.edt_build(DIV); wall = time.perf_counter() - t0
+            ms, attempts = c0.edt_last_build()
+            cold.append((float(ms.sum()), [float(v) for v in ms], attempts, wall))
+            c0.close()
+        best = min(cold)
+        roofline["first_build"] = {"stage_ms": dict(zip(stage_names, best[1])), "kernel_ms_sum": best[0], "attempts": best[2],
+                                   "voxels_per_s": voxels / (best[0] * 1e-3), "pass_x_frac": alg_bytes / (best[1][3] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "call_wall_ms": best[3] * 1e3,
+                                   "note": "best of three fresh contexts; call_wall_ms also holds the allocation of the grids (0.33 GB) and the read-back of the build's counters"}
+    except Exception as exc:
+        roofline["first_build"] = {"error": repr(exc)[:200]}
 
     extra = {}
     roofline_nn = None
+    roofline_lookup = None
+    roofline_bnb = None
     cpu = None
 
     # The legs below share collectives between the ranks: a rank that fails inside one would leave the others waiting
@@ -232,6 +271,7 @@ def main():
             emitted[0] = True
             try:
                 ex, cp, rn = snapshot(extra), snapshot(cpu), snapshot(roofline_nn)
+                rl, rb = snapshot(roofline_lookup), snapshot(roofline_bnb)
                 if timed_out:
                     ex.setdefault("errors", {})["timeout"] = f"legs after the headline exceeded {args.extra_limit} s; line printed without the rest"
                 if rank == 0:
@@ -240,7 +280,7 @@ def main():
                             "vs_baseline": None, "dtype": "int32", "data": "bunny045 scan (40097 points) voxelised on a 300^3 grid",
                             "config": {"workload": "EDT 300^3 from bunny045 (reference box rule), full build per step",
                                        "div": DIV, "occupied_voxels": int(info["occupied"]), "parallelism": "replicas only" if world > 1 else "1 GPU"},
-                            "roofline": roofline, "roofline_nn": rn, "cpu_baseline": cp, "extra": ex}
+                            "roofline": roofline, "roofline_nn": rn, "roofline_lookup": rl, "roofline_bnb": rb, "cpu_baseline": cp, "extra": ex}
                     print(json.dumps(line), flush=True)
             finally:
                 if timed_out:
@@ -265,6 +305,27 @@ def main():
             barrier()
             el = max_over_ranks(time.perf_counter() - t0)
             extra["dt_lookup_queries_per_s"] = world * qrep.shape[0] * 20 / el
+            # the lookup kernel on a batch large enough that its launch does not count: 16 M queries spread over the grid's
+            # box and a little beyond, 20 B per query (12 B in, one 4-byte gather, 4 B out), events on the stream it runs on
+            nq = 1 << 24
+            gen = torch.Generator(device=dev); gen.manual_seed(7)
+            lo_b = torch.tensor(info["min"], device=dev) - 0.02
+            span = float(info["cell"]) * DIV + 0.04
+            qbig = (torch.rand((nq, 3), device=dev, generator=gen) * span + lo_b).contiguous()
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.edt_lookup(qbig)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            times = []
+            for _ in range(10):
+                e0.record(); ctx.edt_lookup(qbig); e1.record(); torch.cuda.synchronize()
+                times.append(e0.elapsed_time(e1))
+            ctx.reset_stream()
+            lk_ms = float(np.median(times))
+            roofline_lookup = {"bound": "hbm", "kernel": "k_edt_lookup", "queries": nq, "algorithmic_bytes_per_launch": 20.0 * nq,
+                               "avg_launch_ms": lk_ms, "achieved": 20.0 * nq / (lk_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": 20.0 * nq / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "queries_per_s": nq / (lk_ms * 1e-3),
+                               "traffic": None, "note": "uniform queries over the whole box: the gather touches all 108 MB of the grid"}
+            del qbig
         except Exception as exc:      # an extra leg must not take the headline line with it
             import traceback; traceback.print_exc()
             extra.setdefault("errors", {})["dt_lookup"] = repr(exc)[:300]
@@ -322,7 +383,7 @@ def main():
                                           "frac": alg / (pass_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                            "converged": {"ms": conv_ms, "achieved": alg / (conv_ms * 1e-3) / 1e9,
                                          "frac": alg / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "queries_per_s": (hi - lo) / (conv_ms * 1e-3)},
-                           "traffic": measured_nn_traffic()}
+                           "traffic": measured_nn_traffic(), "valu_issue_frac_offline": measured_nn_valu_issue()}
             ctx2.close()
             del tgt_s, src_all
         except Exception as exc:      # an extra leg must not take the headline line with it
@@ -421,6 +482,58 @@ def main():
         except Exception as exc:      # an extra leg must not take the headline line with it
             import traceback; traceback.print_exc()
             extra.setdefault("errors", {})["goicp"] = repr(exc)[:300]
+
+        try:
+            # the bound kernel by itself: 512 families of eight sibling translation cubes (4 096 cubes) under random
+            # rotations, lower-bound form at rotation level 3, against the full data cloud; events on the stream it runs on.
+            # Algorithmic bytes: 16 B per data point once per family + the 2-byte gather per (cube, point).
+            if not args.no_goicp:
+                import ctypes as C
+                from icp_amd.host import normalize_goicp
+                gm, gd, _ = normalize_goicp(load_scan("bunny000"), load_scan("bun270"))
+                ctx4 = Context(local)
+                ctx4.set_target(gm); ctx4.edt_build(DIV); ctx4.goicp_set_data(gd)
+                rng = np.random.default_rng(5)
+                fam = 512
+                Rs, cubes, levels = [], [], []
+                for _ in range(fam):
+                    v = rng.uniform(-1.5, 1.5, 3); th = float(np.linalg.norm(v)); a = v / th
+                    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+                    R = (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K).astype(np.float32).reshape(9)
+                    x, y, z = rng.uniform(-0.5, 0.25, 3); w = 0.25
+                    for j in range(8):
+                        Rs.append(R); levels.append(3)
+                        cubes.append([x + (j & 1) * w / 2, y + (j >> 1 & 1) * w / 2, z + (j >> 2 & 1) * w / 2, w / 2])
+                items = ctx4.make_items(Rs, np.asarray(cubes, np.float32), levels)
+                nit = len(items)
+                ctx4.bnb_eval(items)                                   # also makes the 16-bit brick copy of the grid
+                raw = np.frombuffer(C.string_at(C.addressof(items), C.sizeof(items)), np.uint8).copy()
+                items_dev = torch.from_numpy(raw).to(dev)
+                out_dev = torch.zeros(2 * nit, dtype=torch.float64, device=dev)
+                ctx4.set_stream(torch.cuda.current_stream().cuda_stream)
+                ctx4.bnb_eval_noalloc(items_dev, nit, out_dev); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                times = []
+                for _ in range(10):
+                    e0.record(); ctx4.bnb_eval_noalloc(items_dev, nit, out_dev); e1.record(); torch.cuda.synchronize()
+                    times.append(e0.elapsed_time(e1))
+                bn_ms = float(np.median(times))
+                ndp = int(gd.shape[0])
+                alg_b = 2.0 * nit * ndp + 16.0 * ndp * fam
+                pm = _newest_profile("r*_goicp_pmc.json") or {}
+                k8 = next((v for k, v in pm.items() if k.startswith("k_bnb_eval8") and isinstance(v, dict)), None)
+                roofline_bnb = {"bound": "valu issue (not hbm): see valu_issue_frac_offline", "kernel": "k_bnb_eval8 + k_bnb_reduce", "cubes": nit, "points": ndp,
+                                "algorithmic_bytes_per_launch": alg_b, "avg_launch_ms": bn_ms, "achieved": alg_b / (bn_ms * 1e-3) / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_b / (bn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "lookups_per_s": nit * ndp / (bn_ms * 1e-3), "ns_per_cube": bn_ms * 1e6 / nit, "traffic": None,
+                                # vector instructions issued x 4 cycles over the cycles of all 1 024 SIMDs, from the counters of a full
+                                # Go-ICP run under rocprofv3 (offline evidence, profiles/)
+                                "valu_issue_frac_offline": (k8["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (k8["GRBM_GUI_ACTIVE"] / 8.0)
+                                                            if k8 and "SQ_INSTS_VALU" in k8 and k8.get("GRBM_GUI_ACTIVE") else None)}
+                ctx4.close()
+        except Exception as exc:
+            import traceback; traceback.print_exc()
+            extra.setdefault("errors", {})["roofline_bnb"] = repr(exc)[:300]
 
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as O

@@ -43,7 +43,11 @@ int main(int argc, char** argv) {
             const double s = normalize_goicp(*tgt, *src);
             std::printf("normalised by %.6f\n", s);
             GoIcp go(tgt, src, ite, mse, dev);
-            go.frontier_width = 8;
+            // the reference's expansion order (one translation cube per inner search and step); cubes evaluated and
+            // rotation cubes searched ahead of time only fill the launches, every decision stays that of the plain order
+            go.frontier_width = 1;
+            go.lookahead = 1;
+            go.speculate = 255;
             go.registration();
             std::printf("Go-ICP: init %.6f, after ICP %.6f, optimum %.6f (lower bound %.6f, epsilon %.6f), %lld rotation cubes, %lld bound evaluations\noptMat:\n",
                         go.initError, go.icpError, go.optError, go.final_lb, go.sseThresh, go.rot_pops, go.inner_evals);

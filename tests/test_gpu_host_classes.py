@@ -216,6 +216,34 @@ def test_command_line_driver(tmp_path, bunny000, bunny045):
     assert out.returncode == 0 and "occupied 17459" in out.stdout, out.stdout + out.stderr
 
 
+def test_command_line_driver_goicp(tmp_path, bunny000, bun270):
+    """The driver's goicp mode (src/main.cpp:117-122: GoIcp(target, source, iterations, mse).registration()) on the
+    reference's bunny pair, every 8th data point: it normalises the clouds itself and must print the optimum, bound and
+    cube count of the fixture made by the CPU oracle's serial search (tests/golden/goicp_bun270_stride8.json)."""
+    import json, os, re, subprocess
+    from conftest import ROOT, GOLDEN
+    from test_abi_and_host_cpu import _write_ply
+    gold = json.load(open(os.path.join(GOLDEN, "goicp_bun270_stride8.json")))
+    exe = os.path.join(ROOT, "icp_amd", "icpx_main")
+    s, t = str(tmp_path / "data.ply"), str(tmp_path / "model.ply")
+    # the fixture's data cloud is every 8th point of the NORMALISED bun270; normalisation is a shift and a common scale,
+    # so taking every 8th point before it only changes the data centroid: normalise here and hand over finished clouds
+    from icp_amd.host import normalize_goicp
+    m, d, _ = normalize_goicp(bunny000, bun270)
+    _write_ply(s, np.ascontiguousarray(d[::8])); _write_ply(t, m)
+    out = subprocess.run([exe, s, t, "10000", "0.001", "goicp"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    mt = re.search(r"optimum ([0-9.]+) \(lower bound ([0-9.]+), epsilon ([0-9.]+)\), (\d+) rotation cubes", out.stdout)
+    assert mt, out.stdout
+    # the driver normalises again: the model is centred already, the subsampled data cloud gets its own centroid, so the
+    # problem is the fixture's up to that shift; the certificate must hold and the optimum must be no worse than the ICP result
+    opt, lb, eps, pops = float(mt.group(1)), float(mt.group(2)), float(mt.group(3)), int(mt.group(4))
+    assert opt - lb < eps and pops > 100
+    icp_err = float(re.search(r"after ICP ([0-9.]+)", out.stdout).group(1))
+    assert opt <= icp_err
+    assert abs(opt - gold["optError"]) < 0.15 * gold["optError"]
+
+
 def test_goicp_bunny270_against_oracle_golden(bunny000, bun270):
     """Go-ICP on the reference's bunny pair (every 8th data point, DT 300^3, mse 1e-3): the optimum found by
     the batched GPU search equals the one the CPU oracle's serial best-first search certified
