@@ -85,6 +85,7 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
         long long a = 0, b2 = 0;
         if (v && sscanf(v, "%lld,%lld", &a, &b2) == 2 && a >= 0 && b2 >= 0) { ctx->icp_walk_all_tiles = (size_t)a; ctx->icp_ball_min_tiles = (size_t)b2; }
     }
+    { const char* v = getenv("ICPX_CAND"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) { ctx->cand_enable = a != 0; if (a > 1) ctx->cand_max_entries = (size_t)a; } }
     { const char* v = getenv("ICPX_BALL_MANY"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->icp_ball_many = (unsigned)a; }
     // ICPX_BNB_GROUP_MIN: bound batches of at least this many items go through the kernel that takes eight items per
     // workgroup (the tests set 0 and a huge value to compare the two kernels)
@@ -110,7 +111,7 @@ extern "C" void icpx_destroy(icpx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->tgt_xyz, &ctx->cell_start, &ctx->cell_count, &ctx->pyr_masks, &ctx->pyr_tab, &ctx->sorted_pts, &ctx->sort_keys_a, &ctx->sort_keys_b,
-                      &ctx->sort_vals_a, &ctx->sort_vals_b, &ctx->sort_tmp, &ctx->src_pts, &ctx->nn_seed, &ctx->walk_queue, &ctx->tile_counters, &ctx->partials, &ctx->sums,
+                      &ctx->sort_vals_a, &ctx->sort_vals_b, &ctx->sort_tmp, &ctx->cand_tab, &ctx->cand_tmp, &ctx->src_pts, &ctx->nn_seed, &ctx->walk_queue, &ctx->tile_counters, &ctx->partials, &ctx->sums,
                       &ctx->scratch_q, &ctx->scratch_idx, &ctx->scratch_d2, &ctx->scratch_f, &ctx->edt_bits,
                       &ctx->edt_rowlist, &ctx->edt_rowcnt, &ctx->edt_planelist, &ctx->edt_counters, &ctx->trim_keys_a, &ctx->trim_keys_b, &ctx->trim_vals_a, &ctx->trim_vals_b, &ctx->trim_p, &ctx->trim_idx, &ctx->edt_spill, &ctx->edt_plane,
                       &ctx->edt_sq, &ctx->edt_bricks, &ctx->data_pts, &ctx->maxrot, &ctx->bnb_items, &ctx->bnb_partials,

@@ -58,6 +58,11 @@ struct icpx_ctx {
     unsigned pyr_off[11] = {};
     DevBuf sorted_pts;       // nt x float4 {x, y, z, bits(original index)} sorted by cell, ties by index
     DevBuf sort_keys_a, sort_keys_b, sort_vals_a, sort_vals_b, sort_tmp;
+    // candidate table over blocks of 2^cand_shift cells per axis: position in sorted_pts of a target point near the block's centre
+    DevBuf cand_tab, cand_tmp;
+    int cand_dim[3] = {0, 0, 0}, cand_shift = 1;
+    bool cand_ready = false, cand_enable = true;   // ICPX_CAND=0 switches the table off
+    size_t cand_max_entries = 3000000;             // ICPX_CAND=<entries>
 
     // ---- source cloud (ICP) ----------------------------------------------------------------------
     size_t ns = 0;

@@ -42,6 +42,10 @@ struct GridView {
     const unsigned char* __restrict__ masks;   // child masks of all levels >= 1, level l at masks + loff[l]
     const unsigned* __restrict__ loff;          // MAXLEV offsets into masks (device memory)
     int nlev;                                   // number of levels including level 0
+    // candidate table: for every block of 2^cshift cells per axis, the position (in pts) of a target point near the
+    // block's centre (-1 only for an empty target); see k_cand_seed
+    const int* __restrict__ cand;
+    int cdx, cdy, cdz, cshift;
 };
 
 // Cells along one axis at level l: ceil(d / 2^l).
@@ -451,6 +455,65 @@ __global__ __launch_bounds__(256) void k_nn_distance(GridView g, const float* __
     if ((threadIdx.x & 7) == 0) out[i] = (float)__dsqrt_rn(b.d2);
 }
 
+// ---- candidate table -------------------------------------------------------------------------------------------
+// A query that comes without a previous pair (the first pass of an ICP run, every plain nearest-neighbour query) needs a
+// real target point to start from: its distance bounds the search. A greedy descent of the pyramid finds one at the cost
+// of a chain of dependent reads per level and may land far from the nearest point. The table holds, for every block of
+// 2^cshift cells per axis over the grid's box, a target point near the block's centre: the blocks that hold points are
+// seeded with one of theirs, then the entries spread by jump flooding (each block looks at the entries of the 26 blocks
+// `step` away and keeps the one whose point is nearest to its own centre; steps halve down to 1, and 1 once more). What
+// it gives is a candidate about as far as the nearest point plus the block's size; exactness is the search's business.
+__global__ void k_cand_seed(GridView g, int* __restrict__ tab) {
+    const size_t n = (size_t)g.cdx * g.cdy * g.cdz, e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int bk = (int)(e % g.cdz), bj = (int)((e / g.cdz) % g.cdy), bi = (int)(e / ((size_t)g.cdz * g.cdy));
+    const int side = 1 << g.cshift;
+    int found = -1;
+    for (int i = bi * side; i < min((bi + 1) * side, g.dx) && found < 0; i++)
+        for (int j = bj * side; j < min((bj + 1) * side, g.dy) && found < 0; j++) {
+            const size_t row = ((size_t)i * g.dy + j) * g.dz;
+            const int k0 = bk * side, k1 = min((bk + 1) * side, g.dz);
+            const int a = g.start[row + k0], b = g.start[row + k1];
+            if (b > a) found = a;
+        }
+    tab[e] = found;
+}
+
+__global__ void k_cand_flood(GridView g, const int* __restrict__ in, int* __restrict__ out, int step) {
+    const size_t n = (size_t)g.cdx * g.cdy * g.cdz, e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int bk = (int)(e % g.cdz), bj = (int)((e / g.cdz) % g.cdy), bi = (int)(e / ((size_t)g.cdz * g.cdy));
+    const float side = g.h * (float)(1 << g.cshift);
+    const float cx = fmaf((float)bi + 0.5f, side, g.minx), cy = fmaf((float)bj + 0.5f, side, g.miny), cz = fmaf((float)bk + 0.5f, side, g.minz);
+    int best = in[e];
+    float bd = INFINITY;
+    if (best >= 0) { const float4 t = g.pts[best]; const float dx = t.x - cx, dy = t.y - cy, dz = t.z - cz; bd = (dx * dx + dy * dy) + dz * dz; }
+    for (int di = -1; di <= 1; di++)
+        for (int dj = -1; dj <= 1; dj++)
+            for (int dk = -1; dk <= 1; dk++) {
+                const int i = bi + di * step, j = bj + dj * step, k = bk + dk * step;
+                if ((di | dj | dk) == 0 || i < 0 || j < 0 || k < 0 || i >= g.cdx || j >= g.cdy || k >= g.cdz) continue;
+                const int c = in[((size_t)i * g.cdy + j) * g.cdz + k];
+                if (c < 0 || c == best) continue;
+                const float4 t = g.pts[c];
+                const float dx = t.x - cx, dy = t.y - cy, dz = t.z - cz, d = (dx * dx + dy * dy) + dz * dz;
+                if (d < bd) { bd = d; best = c; }
+            }
+    out[e] = best;
+}
+
+// The table's candidate for q, offered to b with its exact distance.
+__device__ __forceinline__ void cand_lookup(const GridView& g, double qx, double qy, double qz, Best& b) {
+    if (!g.cand) return;
+    const int i = cell_coord((float)qx, g.minx, g.inv, g.dx) >> g.cshift, j = cell_coord((float)qy, g.miny, g.inv, g.dy) >> g.cshift,
+              k = cell_coord((float)qz, g.minz, g.inv, g.dz) >> g.cshift;
+    const int at = g.cand[((size_t)i * g.cdy + j) * g.cdz + k];
+    if (at < 0) return;
+    const float4 t = g.pts[at];
+    const double dx = qx - (double)t.x, dy = qy - (double)t.y, dz = qz - (double)t.z;
+    b.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(t.w), at);
+}
+
 struct Mat34 { double m[12]; };
 
 // ---- one ICP pass, a wave per tile of 64 source points ------------------------------------------------------
@@ -494,6 +557,14 @@ constexpr int BALL_MAX_PTS = 4096;       // most points staged for a tile (16 ti
 #define ICPX_BALL_MIN_REACH 4.f
 #endif
 constexpr float BALL_MIN_REACH = ICPX_BALL_MIN_REACH;    // a query at least this many cells from its candidate counts as far from the surface
+#ifndef ICPX_SOLO_MIN
+#define ICPX_SOLO_MIN 3.f
+#endif
+constexpr float SOLO_MIN_REACH = ICPX_SOLO_MIN;  // single open queries at least this many cells from their candidate, and ...
+#ifndef ICPX_SOLO_MAX
+#define ICPX_SOLO_MAX 40.f
+#endif
+constexpr float SOLO_MAX_REACH = ICPX_SOLO_MAX;  // ... less than this many, get a wave of their own (k_icp_solo) instead of a pyramid walk
 constexpr float BALL_MAX_SPREAD = 12.f;  // most cells from the tile's centre to one of its queries, for the same reason
 
 // Minimum / maximum over the lanes of the wave (all of them active), by the device library's cross-lane reduction:
@@ -585,6 +656,28 @@ __device__ unsigned g_nn_tile_t[1 << 18], g_nn_tile_steps[1 << 18], g_nn_tile_to
 #define BALL_T(k) do { } while (0)
 #endif
 
+// Open lanes of a tile (`pend`) go to the queues of their part of the cloud: the walk queue (entries from the front of
+// the part's stretch, counted in qcount[16 part]) or, for a query SOLO_MIN_REACH to SOLO_MAX_REACH cells from the
+// candidate it holds, the queue of k_icp_solo (entries from the back of the same stretch, counted in qcount[16 part + 3];
+// a stretch has a slot for every lane of the part's tiles, so the two cannot meet).
+__device__ __forceinline__ void icp_enqueue_open(unsigned long long pend, bool has_candidate, double d2, float h, size_t shard, unsigned tiles_per_shard,
+                                                 unsigned* __restrict__ queue, unsigned* __restrict__ qcount, unsigned i, int lane) {
+    const double lo = (double)SOLO_MIN_REACH * h, hi = (double)SOLO_MAX_REACH * h;
+    const bool mine = (pend >> lane) & 1ull;
+    const bool solo = mine && has_candidate && d2 >= lo * lo && d2 < hi * hi;
+    const unsigned long long m_solo = __ballot(solo), m_walk = pend & ~m_solo;
+    unsigned at_w = 0, at_s = 0;
+    if (lane == 0) {
+        if (m_walk) at_w = atomicAdd(&qcount[shard * 16], (unsigned)__popcll(m_walk));
+        if (m_solo) at_s = atomicAdd(&qcount[shard * 16 + 3], (unsigned)__popcll(m_solo));
+    }
+    at_w = __shfl(at_w, 0); at_s = __shfl(at_s, 0);
+    const size_t base = shard * (size_t)tiles_per_shard * 64;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (mine && !solo) queue[base + at_w + __popcll(m_walk & below)] = i;
+    if (solo) queue[base + (size_t)tiles_per_shard * 64 - 1 - (at_s + __popcll(m_solo & below))] = i;
+}
+
 __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
                                                               int* __restrict__ idx_out, int* __restrict__ seed, size_t tiles_per_group,
                                                               unsigned long long* __restrict__ counters, unsigned long long counter_base,
@@ -623,6 +716,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         double p[3];
         icp_transform(T, s, p);
         Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);
+        if (b.pos < 0) cand_lookup(g, p[0], p[1], p[2], b);      // no previous pair (a first pass): the table's candidate
         const int cx = cell_coord((float)p[0], g.minx, g.inv, g.dx), cy = cell_coord((float)p[1], g.miny, g.inv, g.dy),
                   cz = cell_coord((float)p[2], g.minz, g.inv, g.dz);
         const double margin = 1e-3 * h + 1e-6 * (fabs(p[0]) + fabs(p[1]) + fabs(p[2]));
@@ -802,11 +896,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
                 far_mask[tile] = pend;
             }
         } else if (pend) {
-            const size_t shard = tile / tiles_per_shard;
-            unsigned at = 0;
-            if (lane == 0) at = atomicAdd(&qcount[shard * 16], (unsigned)__popcll(pend));
-            at = __shfl(at, 0);
-            if ((pend >> lane) & 1ull) queue[shard * tiles_per_shard * 64 + at + __popcll(pend & ((1ull << lane) - 1ull))] = (unsigned)i;
+            icp_enqueue_open(pend, b.pos >= 0, b.d2, g.h, tile / tiles_per_shard, tiles_per_shard, queue, qcount, (unsigned)i, lane);
         }
         if (!valid) continue;
         seed[i] = b.pos;                     // for a queued lane: the candidate its walk starts from
@@ -930,7 +1020,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
         double p[3];
         icp_transform(T, s, p);
         Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);
-        const bool unpaired = __any(mine && b.pos < 0);
+        if (mine && b.pos < 0) cand_lookup(g, p[0], p[1], p[2], b);
+        const bool unpaired = __any(mine && b.pos < 0);          // no table (it is switched off): a greedy descent, then the neighbours' finds
         if (mine && b.pos < 0) greedy_candidate(g, s_loff, p[0], p[1], p[2], b);
         // The lanes' queries are neighbours: try each other's candidates. Only where some lane came without a previous pair
         // (the first pass): what a greedy descent finds can be far off, a previous pair hardly is, and the six dependent
@@ -1139,12 +1230,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
         if (lane == 0) { atomicAdd(&g_nn_stats[2], 1ull); atomicAdd(&g_nn_stats[3], __popcll(pend) < __popcll(open) ? 1ull : 0ull); atomicAdd(&g_nn_stats[4], (unsigned long long)staged_pts);
                          atomicAdd(&g_nn_stats[5], (unsigned long long)__popcll(pend)); atomicAdd(&g_nn_stats[12], k_near); }
 #endif
-        if (pend) {
-            unsigned at = 0;
-            if (lane == 0) at = atomicAdd(&qcount[shard * 16], (unsigned)__popcll(pend));
-            at = __shfl(at, 0);
-            if ((pend >> lane) & 1ull) queue[(size_t)shard * tiles_per_shard * 64 + at + __popcll(pend & ((1ull << lane) - 1ull))] = (unsigned)i;
-        }
+        if (pend) icp_enqueue_open(pend, b.pos >= 0, b.d2, g.h, shard, tiles_per_shard, queue, qcount, (unsigned)i, lane);
         if (!mine) continue;
         seed[i] = b.pos;
         if (settled && idx_out) idx_out[__float_as_int(s.w)] = b.idx;
@@ -1172,7 +1258,9 @@ __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __re
             const float4 s = src[i];
             double p[3];
             icp_transform(T, s, p);
-            const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(g, seed, i, nt, p[0], p[1], p[2]));
+            Best b0 = best_seed(g, seed, i, nt, p[0], p[1], p[2]);
+            if (b0.pos < 0) cand_lookup(g, p[0], p[1], p[2], b0);
+            const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, b0);
             if ((threadIdx.x & 7) != 0) continue;
             seed[i] = b.pos;
             if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
@@ -1196,6 +1284,93 @@ __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __re
         if ((threadIdx.x & 7) != 0) continue;
         seed[i] = b.pos;
         if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
+    }
+}
+
+// The queries k_icp_tile and k_icp_ball left open that are several cells from their candidate: a wave each. Such a query's
+// pyramid walk expands a hundred nodes and more, one after the other, each a chain of dependent reads: the walk kernel
+// then lasts as long as its longest walk (half a millisecond in the early passes of a million points) with most of the
+// GPU idle. Here the 64 lanes share the ball around the query whose radius is the candidate's distance: lane l takes
+// columns l, l + 64, ... of the cells under the ball, reads the two ends of the column's chord from cell_start and scans
+// the chord's points (float distance first, the exact one for points the float value cannot rule out); the lanes'
+// results are reduced by (distance, index). Every point as near as the candidate lies in the ball, so the result is the
+// exact nearest point with the lowest index, as from the walk.
+__global__ __launch_bounds__(256) void k_icp_solo(GridView g, const float4* __restrict__ src, Mat34 T, size_t nt, const unsigned* __restrict__ queue,
+                                                  const unsigned* __restrict__ qcount, unsigned tiles_per_shard, int* __restrict__ idx_out, int* __restrict__ seed) {
+    __shared__ unsigned s_count[WALK_SHARDS];
+    if (threadIdx.x < WALK_SHARDS) s_count[threadIdx.x] = qcount[threadIdx.x * 16 + 3];
+    __syncthreads();
+    unsigned most = 0;
+    for (int r = 0; r < WALK_SHARDS; r++) most = max(most, s_count[r]);
+    const int lane = (int)(threadIdx.x & 63);
+    const size_t nwaves = (size_t)gridDim.x * 4, items = (size_t)most * WALK_SHARDS;
+    const float h = g.h;
+    // items are numbered part by part; the four waves of a workgroup take four consecutive ones
+    for (size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < items; item += nwaves) {
+        const unsigned shard = (unsigned)(item / most), e = (unsigned)(item % most);
+        if (e >= s_count[shard]) continue;
+        const size_t i = queue[(size_t)shard * tiles_per_shard * 64 + (size_t)tiles_per_shard * 64 - 1 - e];
+        const float4 s = src[i];
+        double p[3];
+        icp_transform(T, s, p);
+        Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);     // the same in every lane; present, or the query would not be here
+        const QueryF f(p[0], p[1], p[2], (double)h);
+        const float r = (float)__dsqrt_rn(b.d2);
+        const float Rw = r * (1.f + 1e-5f) + 0.02f * h, R2 = Rw * Rw;
+        const float qx = f.x, qy = f.y, qz = f.z;
+        const int w = (int)(Rw * g.inv) + 2;
+        const int ccx = (int)floorf((qx - g.minx) * g.inv), ccy = (int)floorf((qy - g.miny) * g.inv);
+        const int x0 = max(ccx - w, 0), x1 = min(ccx + w, g.dx - 1), y0 = max(ccy - w, 0), y1 = min(ccy + w, g.dy - 1);
+        const int nby = max(y1 - y0 + 1, 1);
+        const int ncols = max(x1 - x0 + 1, 0) * max(y1 - y0 + 1, 0);
+        float thr = f.point_threshold(b.d2);
+        constexpr int AHEAD = 4;            // columns per lane whose cell_start reads are in flight together
+        for (int c0 = 0; c0 < ncols; c0 += 64 * AHEAD) {
+            int firsts[AHEAD], ends[AHEAD];
+#pragma unroll
+            for (int a = 0; a < AHEAD; a++) {
+                const int c = c0 + 64 * a + lane;
+                firsts[a] = 0; ends[a] = 0;
+                if (c < ncols) {
+                    const int ci = x0 + c / nby, cj = y0 + c % nby;
+                    const float lx = fmaf((float)ci, h, g.minx), ly = fmaf((float)cj, h, g.miny);
+                    const float dx = fmaxf(fmaxf(lx - qx, qx - (lx + h)), 0.f), dy = fmaxf(fmaxf(ly - qy, qy - (ly + h)), 0.f);
+                    const float rest = R2 - (dx * dx + dy * dy);
+                    if (rest >= 0.f) {
+                        const float half = __fsqrt_rn(rest);
+                        const int k0 = max((int)floorf((qz - half - g.minz) * g.inv - 0.02f), 0);
+                        const int k1 = min((int)floorf((qz + half - g.minz) * g.inv + 0.02f), g.dz - 1);
+                        if (k0 <= k1) {
+                            const size_t cbase = ((size_t)ci * g.dy + cj) * g.dz;
+                            firsts[a] = g.start[cbase + k0];
+                            ends[a] = g.start[cbase + k1 + 1];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < AHEAD; a++)
+                for (int k = firsts[a]; k < ends[a]; k++) {
+                    const float4 t = g.pts[k];
+                    const float fx = qx - t.x, fy = qy - t.y, fz = qz - t.z;
+                    const float sf = (fx * fx + fy * fy) + fz * fz;
+                    if (sf > thr) continue;
+                    const double ex = p[0] - (double)t.x, ey = p[1] - (double)t.y, ez = p[2] - (double)t.z;
+                    b.offer((ex * ex + ey * ey) + ez * ez, __float_as_int(t.w), k);
+                    thr = f.point_threshold(b.d2);
+                }
+        }
+        // minimum by (distance, index) over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double d = __shfl_xor(b.d2, o);
+            const int id = __shfl_xor(b.idx, o), at = __shfl_xor(b.pos, o);
+            if (d < b.d2 || (d == b.d2 && id < b.idx)) { b.d2 = d; b.idx = id; b.pos = at; }
+        }
+        if (lane == 0) {
+            seed[i] = b.pos;
+            if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
+        }
     }
 }
 
@@ -1289,14 +1464,14 @@ __global__ __launch_bounds__(256) void k_icp_trim_sums(const unsigned* __restric
         partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
-// clear16: nclear triples of words, 16 words apart, set to zero on the way (nullptr: none).
+// clear16: nclear groups of four words, 16 words apart, set to zero on the way (nullptr: none).
 // Fixed-order final reduction of the block partials (component-major: partials[component * nblocks + block]): one
 // workgroup per component, thread t adds blocks t, t + 256, ... in that order, then a tree over the threads.
 __global__ __launch_bounds__(256) void k_reduce_sums(const double* __restrict__ partials, int nblocks, double* __restrict__ sums,
                                                      unsigned* __restrict__ clear16 = nullptr, int nclear = 0) {
     __shared__ double sm[256];
     if (clear16 && blockIdx.x == 0 && (int)threadIdx.x < nclear) {   // the queues' counters and the hand-out counters of k_icp_ball, for the next pass
-        clear16[threadIdx.x * 16] = 0u; clear16[threadIdx.x * 16 + 1] = 0u; clear16[threadIdx.x * 16 + 2] = 0u;
+        clear16[threadIdx.x * 16] = 0u; clear16[threadIdx.x * 16 + 1] = 0u; clear16[threadIdx.x * 16 + 2] = 0u; clear16[threadIdx.x * 16 + 3] = 0u;
     }
     const double* row = partials + (size_t)blockIdx.x * nblocks;
     double v = 0.0;
@@ -1320,6 +1495,8 @@ GridView view_of(const icpx_ctx* ctx) {
     g.masks = ctx->pyr_masks.as<unsigned char>();
     g.loff = ctx->pyr_tab.as<unsigned>();
     g.nlev = ctx->pyr_nlev;
+    g.cand = ctx->cand_ready ? ctx->cand_tab.as<int>() : nullptr;
+    g.cdx = ctx->cand_dim[0]; g.cdy = ctx->cand_dim[1]; g.cdz = ctx->cand_dim[2]; g.cshift = ctx->cand_shift;
     return g;
 }
 
@@ -1424,6 +1601,34 @@ int icpx_grid_build(icpx_ctx* ctx) {
                 hipLaunchKernelGGL(k_pyr_from_masks, dim3(nb), dim3(256), 0, ctx->stream, fl + ctx->pyr_off[l - 1], lo[0], lo[1], lo[2], upw, up[1], up[2]);
         }
         ICPX_TRY(icpx_launch_check(ctx, "pyramid kernels"));
+    }
+    // candidate table (see k_cand_seed): blocks of 2^shift cells per axis, the smallest shift that keeps the table
+    // below two million entries (a million points: 254^3 cells, blocks of 2, 2.1 M / 8 ... )
+    ctx->cand_ready = false;
+    if (ctx->cand_enable) {
+        int shift = 1;
+        for (;;) {
+            size_t n = 1;
+            for (int c = 0; c < 3; c++) { ctx->cand_dim[c] = (ctx->gdim[c] + (1 << shift) - 1) >> shift; n *= (size_t)ctx->cand_dim[c]; }
+            if (n <= (size_t)ctx->cand_max_entries || shift >= 8) break;
+            shift++;
+        }
+        ctx->cand_shift = shift;
+        const size_t n = (size_t)ctx->cand_dim[0] * ctx->cand_dim[1] * ctx->cand_dim[2];
+        ICPX_TRY(icpx_reserve(ctx, ctx->cand_tab, n * sizeof(int)));
+        ICPX_TRY(icpx_reserve(ctx, ctx->cand_tmp, n * sizeof(int)));
+        GridView g = view_of(ctx);
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        int* a = ctx->cand_tab.as<int>(); int* b = ctx->cand_tmp.as<int>();
+        hipLaunchKernelGGL(k_cand_seed, dim3(nb), dim3(256), 0, ctx->stream, g, a);
+        int top = 1;
+        while (top * 2 < std::max(ctx->cand_dim[0], std::max(ctx->cand_dim[1], ctx->cand_dim[2]))) top *= 2;
+        int rounds = 0;
+        for (int step = top; step >= 1; step >>= 1, rounds++) { hipLaunchKernelGGL(k_cand_flood, dim3(nb), dim3(256), 0, ctx->stream, g, (const int*)a, b, step); std::swap(a, b); }
+        hipLaunchKernelGGL(k_cand_flood, dim3(nb), dim3(256), 0, ctx->stream, g, (const int*)a, b, 1); std::swap(a, b); rounds++;
+        if (a != ctx->cand_tab.as<int>()) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->cand_tab.p, a, n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        ICPX_TRY(icpx_launch_check(ctx, "candidate table kernels"));
+        ctx->cand_ready = true;
     }
     ctx->grid_ready = true;
     return ICPX_OK;
@@ -1579,6 +1784,9 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     if (use_ball)
         hipLaunchKernelGGL(k_icp_ball, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
                            ctx->nn_seed.as<int>(), far_queue, far_mask, queue, qcount, tiles_per_shard, ctx->icp_ball_many);
+    if (!walk_all)
+        hipLaunchKernelGGL(k_icp_solo, dim3((unsigned)std::min<size_t>((ctx->ns + 255) / 256, (size_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
+                           queue, qcount, tiles_per_shard, idx_dev, ctx->nn_seed.as<int>());
     const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, (size_t)ctx->num_cus * 8 / WALK_SHARDS) * WALK_SHARDS);
     const unsigned all_blocks = (unsigned)std::min<size_t>((ctx->ns + NN_OCTETS - 1) / NN_OCTETS, (size_t)ctx->num_cus * 8);
     hipLaunchKernelGGL(k_icp_walk, dim3(walk_all ? all_blocks : std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,

@@ -14,7 +14,7 @@ for r in rows:
     m = re.search(r"\bk_\w+", r["Kernel_Name"])
     name = m.group(0) if m else r["Kernel_Name"]
     per[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-for k in ("k_icp_tile", "k_icp_ball", "k_icp_walk", "k_icp_sums", "k_reduce_sums"):
+for k in ("k_icp_tile", "k_icp_ball", "k_icp_solo", "k_icp_walk", "k_icp_sums", "k_reduce_sums"):
     d = per.get(k, [])
     print(k, "us per pass:", [round(x) for x in d[:40]])
 PY
