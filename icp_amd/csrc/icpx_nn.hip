@@ -403,6 +403,8 @@ __device__ __forceinline__ Best best_seed(const GridView& g, const int* __restri
     return b;
 }
 
+__device__ __forceinline__ void cand_lookup(const GridView& g, double qx, double qy, double qz, Best& b);   // the candidate table, below
+
 // K nearest target points of every query, ascending by (squared distance, index); slots beyond the number
 // of target points get index -1 and an infinite distance.
 template <int K>
@@ -436,7 +438,9 @@ __global__ __launch_bounds__(256) void k_nn(GridView g, const double* __restrict
     __syncthreads();
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;   // eight lanes per query
     if (i >= n) return;
-    const Best b = nn_search8(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_empty());
+    Best b0 = best_empty();
+    cand_lookup(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], b0);      // a real point to start from: its distance prunes the walk
+    const Best b = nn_search8(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, b0);
     if ((threadIdx.x & 7) == 0) {
         if (idx) idx[i] = b.idx;
         if (d2) d2[i] = b.d2;
@@ -451,7 +455,9 @@ __global__ __launch_bounds__(256) void k_nn_distance(GridView g, const float* __
     __syncthreads();
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     if (i >= n) return;
-    const Best b = nn_search8(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_empty());
+    Best b0 = best_empty();
+    cand_lookup(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2], b0);
+    const Best b = nn_search8(g, (double)q[3 * i], (double)q[3 * i + 1], (double)q[3 * i + 2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, b0);
     if ((threadIdx.x & 7) == 0) out[i] = (float)__dsqrt_rn(b.d2);
 }
 
@@ -558,9 +564,9 @@ constexpr int BALL_MAX_PTS = 4096;       // most points staged for a tile (16 ti
 #endif
 constexpr float BALL_MIN_REACH = ICPX_BALL_MIN_REACH;    // a query at least this many cells from its candidate counts as far from the surface
 #ifndef ICPX_SOLO_MIN
-#define ICPX_SOLO_MIN 3.f
+#define ICPX_SOLO_MIN 0.f
 #endif
-constexpr float SOLO_MIN_REACH = ICPX_SOLO_MIN;  // single open queries at least this many cells from their candidate, and ...
+constexpr float SOLO_MIN_REACH = ICPX_SOLO_MIN;  // single open queries at least this many cells from their candidate (1 M pair, 30 passes: 14.0 / 13.6 / 12.8 / 12.6 ms for 3 / 2 / 1 / 0), and ...
 #ifndef ICPX_SOLO_MAX
 #define ICPX_SOLO_MAX 40.f
 #endif
@@ -571,12 +577,6 @@ constexpr float BALL_MAX_SPREAD = 12.f;  // most cells from the tile's centre to
 // register-to-register row operations, where six rounds of __shfl_xor go through the LDS crossbar one after the other.
 __device__ __forceinline__ int wave_min(int v) { return __ockl_wfred_min_i32(v); }
 __device__ __forceinline__ int wave_max(int v) { return __ockl_wfred_max_i32(v); }
-
-// Float threshold above which a candidate's float squared distance proves it strictly farther than `best` (see above).
-__device__ __forceinline__ float prune_threshold(double best, double slack) {
-    const double r = __dsqrt_rn(best) + slack;
-    return (float)(r * r * (1.0 + 0x1p-20) * (1.0 + 0x1p-22));   // the second factor outweighs the rounding of the conversion
-}
 
 __device__ __forceinline__ void icp_transform(const Mat34& T, const float4 s, double p[3]) {
 #pragma unroll
@@ -756,7 +756,13 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         // Stage the box unless that is clearly wasted: when most lanes already hold a candidate (their previous
         // pair) and hardly any of those is near enough for the box to settle the query.
         const int seeded = __popcll(__ballot(b.pos >= 0)), promising = __popcll(__ballot(near_lane || (b.pos >= 0 && outside > b.d2)));
-        bool staged = ncols <= TILE_COLS && !(seeded >= 32 && promising < 8);
+#ifndef ICPX_FAR_SKIP
+#define ICPX_FAR_SKIP 8
+#endif
+        // (a tile with this many lanes far from their candidates goes to k_icp_ball whatever the box settles, and that kernel
+        // takes the tile's near lanes along)
+        const int far_now = __popcll(__ballot(valid && b.pos >= 0 && !(b.d2 < (double)BALL_MIN_REACH * h * (double)BALL_MIN_REACH * h)));
+        bool staged = ncols <= TILE_COLS && !(seeded >= 32 && promising < 8) && !(far_queue && far_now >= ICPX_FAR_SKIP);
         int total = 0;
 #ifdef ICPX_NN_STATS
         if (lane == 0) { atomicAdd(&g_nn_stats[0], 1ull); atomicAdd(&g_nn_stats[6], (unsigned long long)ncols); }
@@ -802,15 +808,22 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         }
         bool ambiguous = false;
         if (staged) {
-            // A branch-free float pass over the box's points, every lane against every point (read from LDS as
-            // broadcasts, four points per read and coordinate; two points per packed float instruction). The low bits
-            // (TILE_CAP - 1) of every float squared distance are replaced by the point's slot in the staging area, so
-            // the smallest such word, u1, names its candidate; u2 is the second smallest. Distances are not negative,
-            // so the words order like the values.
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            const f2 qx2 = {(float)p[0], (float)p[0]}, qy2 = {(float)p[1], (float)p[1]}, qz2 = {(float)p[2], (float)p[2]};
-            unsigned u1 = 0x7f800000u, u2 = 0x7f800000u;          // +infinity
-            int vlo = 0;                     // first list position of the part of the box u1 was found in
+            // A branch-free float pass over the box's points, every lane against every point (read from LDS as broadcasts,
+            // four points per read and coordinate). Distances are taken relative to an origin c near the tile (the first
+            // lane's query, as a float): with t' = fl(t - c), w = fl(|t'|^2) (staged once per point) and q' = fl(q - c), the
+            // three multiply-adds s = w - 2 q'.t' differ from |q - t|^2 - |q - c|^2 by at most 8.1 u (|t'|^2 + 2 |q'| |t'|),
+            // u = 2^-24 (one rounding per coordinate of t' and q', three in w, three in s, each relative to a partial result
+            // no larger than that; the result has the size of its largest term, nothing cancels). The lane keeps the smallest
+            // s, its place in the list, and the second smallest. (An earlier version compared |q - t|^2 itself with the
+            // point's slot in the low nine bits of the float: five to ten in a hundred lanes a few cells from the surface
+            // then had two candidates too close to call, 15 000 walks per pass of a million points.)
+            const float cxf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)p[0])));
+            const float cyf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)p[1])));
+            const float czf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)p[2])));
+            const double ex = p[0] - (double)cxf, ey = p[1] - (double)cyf, ez = p[2] - (double)czf, qb2 = (ex * ex + ey * ey) + ez * ez;
+            const float mx = -2.f * (float)ex, my = -2.f * (float)ey, mz = -2.f * (float)ez;
+            float u1 = INFINITY, u2 = INFINITY, wmax = 0.f;
+            int i1 = -1;                     // list position of the smallest
             for (int lo = 0; lo < total; lo += TILE_CAP) {
                 const int hi = min(lo + TILE_CAP, total), m = hi - lo;
                 wave_sync();                 // column tables written / the previous part has been compared
@@ -827,56 +840,46 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
                     }
                     if (v < hi) {
                         const float4 t = g.pts[s_first[col] + (v - s_pre[col])];
-                        s_x[v - lo] = t.x; s_y[v - lo] = t.y; s_z[v - lo] = t.z; s_w[v - lo] = __int_as_float(v - lo);
+                        const float tx = t.x - cxf, ty = t.y - cyf, tz = t.z - czf, w = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+                        s_x[v - lo] = tx; s_y[v - lo] = ty; s_z[v - lo] = tz; s_w[v - lo] = w;
+                        wmax = fmaxf(wmax, w);
                     }
                 }
-                // up to seven far-away points fill the last group of eight
-                if (lane < ((8 - (m & 7)) & 7)) { s_x[m + lane] = 3e18f; s_y[m + lane] = 3e18f; s_z[m + lane] = 3e18f; s_w[m + lane] = __int_as_float(m + lane); }
+                // up to three far-away points fill the last group of four
+                if (lane < ((4 - (m & 3)) & 3)) { s_x[m + lane] = 0.f; s_y[m + lane] = 0.f; s_z[m + lane] = 0.f; s_w[m + lane] = 3e37f; }
                 wave_sync();
 #ifdef ICPX_NN_STATS
                 tile_steps += m;
 #endif
-                const unsigned before = u1;
-                const unsigned keep = ~(unsigned)(TILE_CAP - 1);
-                // the two smallest of {u1 <= u2, a, b}
-                auto take2 = [&](unsigned a, unsigned b) {
-                    const unsigned lo2 = min(a, b), hi2 = max(a, b), c = min(u2, hi2);
-                    unsigned mid;
-                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(mid) : "v"(u1), "v"(lo2), "v"(c));   // c >= min(u1, lo2): the second smallest of the four
-                    u2 = mid;
-                    u1 = min(u1, lo2);
-                };
-                auto four = [&](const float4 X, const float4 Y, const float4 Z, const float4 W) {
-                    const f2 dxa = qx2 - f2{X.x, X.y}, dya = qy2 - f2{Y.x, Y.y}, dza = qz2 - f2{Z.x, Z.y};
-                    const f2 dxb = qx2 - f2{X.z, X.w}, dyb = qy2 - f2{Y.z, Y.w}, dzb = qz2 - f2{Z.z, Z.w};
-                    const f2 sa = __builtin_elementwise_fma(dza, dza, __builtin_elementwise_fma(dya, dya, dxa * dxa));
-                    const f2 sb = __builtin_elementwise_fma(dzb, dzb, __builtin_elementwise_fma(dyb, dyb, dxb * dxb));
-                    take2((__float_as_uint(sa.x) & keep) | __float_as_uint(W.x), (__float_as_uint(sa.y) & keep) | __float_as_uint(W.y));
-                    take2((__float_as_uint(sb.x) & keep) | __float_as_uint(W.z), (__float_as_uint(sb.y) & keep) | __float_as_uint(W.w));
-                };
-                for (int k = 0; k < m; k += 8) {
-                    const float4 X0 = *reinterpret_cast<const float4*>(s_x + k), Y0 = *reinterpret_cast<const float4*>(s_y + k),
-                                 Z0 = *reinterpret_cast<const float4*>(s_z + k), W0 = *reinterpret_cast<const float4*>(s_w + k);
-                    const float4 X1 = *reinterpret_cast<const float4*>(s_x + k + 4), Y1 = *reinterpret_cast<const float4*>(s_y + k + 4),
-                                 Z1 = *reinterpret_cast<const float4*>(s_z + k + 4), W1 = *reinterpret_cast<const float4*>(s_w + k + 4);
-                    four(X0, Y0, Z0, W0);
-                    four(X1, Y1, Z1, W1);
+                for (int k = 0; k < m; k += 4) {
+                    const float4 X = *reinterpret_cast<const float4*>(s_x + k), Y = *reinterpret_cast<const float4*>(s_y + k),
+                                 Z = *reinterpret_cast<const float4*>(s_z + k), W = *reinterpret_cast<const float4*>(s_w + k);
+                    const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w}, ws[4] = {W.x, W.y, W.z, W.w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float sf = fmaf(mx, xs[j], fmaf(my, ys[j], fmaf(mz, zs[j], ws[j])));   // |t - q|^2 - |q - c|^2
+                        i1 = sf < u1 ? lo + k + j : i1;
+                        u2 = __builtin_amdgcn_fmed3f(u1, u2, sf);     // u1 <= u2: the second smallest of the three
+                        u1 = fminf(u1, sf);
+                    }
                 }
-                if (u1 != before) vlo = lo;
             }
-            // Then the exact distance of that one candidate. It is the nearest of the box's points, alone, unless
-            // another one's float distance is within the rounding slack of it (see prune_threshold; the slot bits add
-            // 2^-14 each way): about one lane in a few thousand, which is left to the walk, with this candidate to start from.
-            if (u1 < 0x7f800000u) {
-                const int vbest = vlo + (int)(u1 & (unsigned)(TILE_CAP - 1));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));   // the largest |t'|^2 of the box (all lanes are here)
+            // Then the exact distance of that one candidate. Every other staged point B has |q - B|^2 >= u2 + |q - c|^2 - E
+            // with E the error bound above over all staged points: strictly farther when that exceeds the winner's
+            // distance. Otherwise two candidates are too close to call in float and the lane is left to the walk, with
+            // this candidate to start from.
+            if (i1 >= 0) {
                 int c = 0, hi = ncols - 1;   // the candidate's column: the last one that starts at or before it
-                while (c < hi) { const int mid = (c + hi + 1) >> 1; if (s_pre[mid] <= vbest) c = mid; else hi = mid - 1; }
-                const int at = s_first[c] + (vbest - s_pre[c]);
+                while (c < hi) { const int mid = (c + hi + 1) >> 1; if (s_pre[mid] <= i1) c = mid; else hi = mid - 1; }
+                const int at = s_first[c] + (i1 - s_pre[c]);
                 const float4 t = g.pts[at];
-                const double ex = p[0] - (double)t.x, ey = p[1] - (double)t.y, ez = p[2] - (double)t.z;
-                const double d = (ex * ex + ey * ey) + ez * ez;
-                const float thr = prune_threshold(d, 0x1.000002p-24 * (fabs(p[0]) + fabs(p[1]) + fabs(p[2])));
-                ambiguous = !(__uint_as_float(u2) > thr * (1.0f + 0x1p-12f));
+                const double fx = p[0] - (double)t.x, fy = p[1] - (double)t.y, fz = p[2] - (double)t.z;
+                const double d = (fx * fx + fy * fy) + fz * fz;
+                const double tn = (double)__fsqrt_rn(wmax) * (1.0 + 1e-6), qn = __dsqrt_rn(qb2);
+                const double E = 10.0 * 0x1p-24 * (tn * tn + 2.0 * qn * tn) + 1e-30;
+                ambiguous = !((double)u2 > (d - qb2) + E);
                 b.offer(d, __float_as_int(t.w), at);
             }
         }
@@ -885,6 +888,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         if (lane == 0 && tile < (1u << 18)) { g_nn_tile_t[tile] = (unsigned)(wall_clock64() - tile_t0); g_nn_tile_steps[tile] = tile_steps; g_nn_tile_total[tile] = (unsigned)total; }
 #endif
         const unsigned long long pend = __ballot(valid && !settled);
+#ifdef ICPX_NN_STATS
+        { const unsigned long long na = __popcll(__ballot(valid && staged && ambiguous)), nu = staged ? 0ull : (unsigned long long)__popcll(pend);
+          if (lane == 0) { atomicAdd(&g_nn_stats[14], na); atomicAdd(&g_nn_stats[15], nu); } }
+#endif
         // open lanes without a candidate, or BALL_MIN_REACH cells and more from it (k_icp_ball's test for a far query)
         const double reach2 = (double)BALL_MIN_REACH * h * (double)BALL_MIN_REACH * h;
         const int far_lanes = __popcll(__ballot(valid && !settled && !(b.d2 < reach2)));
@@ -1787,7 +1794,9 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     if (!walk_all)
         hipLaunchKernelGGL(k_icp_solo, dim3((unsigned)std::min<size_t>((ctx->ns + 255) / 256, (size_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
                            queue, qcount, tiles_per_shard, idx_dev, ctx->nn_seed.as<int>());
-    const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, (size_t)ctx->num_cus * 8 / WALK_SHARDS) * WALK_SHARDS);
+    // (what is left to the walk when the tile kernels ran: queries without any candidate, or absurdly far from theirs; the
+    // grid is small because launching two thousand workgroups that find nothing to do costs 25 us a pass)
+    const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, (size_t)ctx->num_cus * 2 / WALK_SHARDS) * WALK_SHARDS);
     const unsigned all_blocks = (unsigned)std::min<size_t>((ctx->ns + NN_OCTETS - 1) / NN_OCTETS, (size_t)ctx->num_cus * 8);
     hipLaunchKernelGGL(k_icp_walk, dim3(walk_all ? all_blocks : std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
                        queue, qcount, tiles_per_shard, idx_dev, ctx->nn_seed.as<int>(), walk_all ? ctx->ns : (size_t)0);
@@ -1802,7 +1811,7 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
         fprintf(stderr, "tiles %llu staged %llu cols/tile %.1f pts/staged tile %.1f; far tiles %llu covered %llu pts/covered %.0f lanes left to the walk %llu\n", h[0], h[1], (double)h[6] / h[0], (double)h[7] / (h[1] ? h[1] : 1),
                 h[2], h[3], (double)h[4] / (h[3] ? h[3] : 1), h[5]);
         fprintf(stderr, "   BALL left: near %llu, part<8 %llu, spread %llu, columns %llu, points %llu\n", h[12], h[8], h[9], h[10], h[11]);
-        fprintf(stderr, "   WALKQ %llu\n", h[13]);
+        fprintf(stderr, "   WALKQ %llu; tile kernel: ambiguous lanes %llu, lanes of unstaged tiles %llu\n", h[13], h[14], h[15]);
         { unsigned long long bt[8], zz[8] = {0}; hipMemcpyFromSymbol(bt, HIP_SYMBOL(g_ball_t), sizeof bt); hipMemcpyToSymbol(HIP_SYMBOL(g_ball_t), zz, sizeof zz);
           fprintf(stderr, "   BALLT us per far tile: candidates %.1f geometry %.1f columns %.1f staging %.1f compare %.1f resolve %.1f | tile %.1f\n", bt[0] / 100.0 / (h[2] ? h[2] : 1), bt[1] / 100.0 / (h[2] ? h[2] : 1),
                   bt[2] / 100.0 / (h[2] ? h[2] : 1), bt[3] / 100.0 / (h[2] ? h[2] : 1), bt[4] / 100.0 / (h[2] ? h[2] : 1), bt[5] / 100.0 / (h[2] ? h[2] : 1), bt[6] / 100.0 / (h[2] ? h[2] : 1)); }
