@@ -1715,6 +1715,8 @@ extern "C" int icpx_nn_distance(icpx_ctx* ctx, const float* q_xyz, size_t n, int
     return ICPX_OK;
 }
 
+static int icp_step_reserve(icpx_ctx* ctx);
+
 extern "C" int icpx_set_source(icpx_ctx* ctx, const float* xyz, size_t n, size_t stride_bytes, int where) {
     if (!ctx) return ICPX_EINVAL;
     if (!xyz || n == 0) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_set_source: empty source cloud");
@@ -1732,8 +1734,33 @@ extern "C" int icpx_set_source(icpx_ctx* ctx, const float* xyz, size_t n, size_t
     // correspondences of the last pass, by sorted position (-1 = none): the next pass starts its search from them
     ICPX_TRY(icpx_reserve(ctx, ctx->nn_seed, n * sizeof(int)));
     ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->nn_seed.p, 0xff, n * sizeof(int), ctx->stream));
-    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->ns = n;
+    ICPX_TRY(icp_step_reserve(ctx));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+// Working memory of an ICP pass for the current source cloud: per-wave partial sums, the tile hand-out counters, the
+// queues. Reserved when the source is set, so that the first pass allocates nothing (an allocation inside a pass stalls
+// the stream for a millisecond).
+static int icp_step_reserve(icpx_ctx* ctx) {
+    const size_t tiles = (ctx->ns + 63) / 64;
+    const int sblocks = (int)((std::min<size_t>((tiles + TILE_WAVES - 1) / TILE_WAVES, (size_t)ctx->num_cus * 8) + 7) / 8 * 8);
+    ICPX_TRY(icpx_reserve(ctx, ctx->partials, (size_t)sblocks * TILE_WAVES * ICPX_NSUMS * sizeof(double)));
+    if (!ctx->tile_counters.p) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->tile_counters, 8 * 64));
+        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->tile_counters.p, 0, 8 * 64, ctx->stream));
+        ctx->tile_counter_base = 0;
+    }
+    const unsigned tiles_per_shard = (unsigned)((tiles + WALK_SHARDS - 1) / WALK_SHARDS);
+    const size_t far_off = (size_t)WALK_SHARDS * 16 + (size_t)WALK_SHARDS * tiles_per_shard * 64;
+    const size_t mask_off = (far_off + (size_t)WALK_SHARDS * tiles_per_shard + 1) / 2 * 2;
+    const size_t queue_words = mask_off + 2 * (size_t)WALK_SHARDS * tiles_per_shard;
+    if (ctx->walk_queue.cap < queue_words * sizeof(unsigned)) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->walk_queue, queue_words * sizeof(unsigned)));
+        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->walk_queue.p, 0, WALK_SHARDS * 16 * sizeof(unsigned), ctx->stream));   // later passes: k_reduce_sums
+    }
+    ICPX_TRY(icpx_reserve(ctx, ctx->sums, ICPX_NSUMS * sizeof(double)));
     return ICPX_OK;
 }
 
@@ -1749,22 +1776,13 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     const int sblocks = (int)((std::min<size_t>((tiles + TILE_WAVES - 1) / TILE_WAVES, (size_t)ctx->num_cus * 8) + 7) / 8 * 8);
     const int swaves = sblocks * TILE_WAVES;
     const int tiles_per_sblock = (int)((tiles + swaves - 1) / swaves);
-    ICPX_TRY(icpx_reserve(ctx, ctx->partials, (size_t)swaves * ICPX_NSUMS * sizeof(double)));
-    // the eight tile counters (64 B apart), the per-tile counts of queued points, the queue (64 entries per tile)
-    if (!ctx->tile_counters.p) {
-        ICPX_TRY(icpx_reserve(ctx, ctx->tile_counters, 8 * 64));
-        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->tile_counters.p, 0, 8 * 64, ctx->stream));
-        ctx->tile_counter_base = 0;
-    }
+    // the partial sums, the eight tile counters (64 B apart), the per-part counts of queued points and the queues (64
+    // entries per tile): reserved by icpx_set_source, here only for a context whose source was set before a resize
+    ICPX_TRY(icp_step_reserve(ctx));
     const unsigned tiles_per_shard = (unsigned)((tiles + WALK_SHARDS - 1) / WALK_SHARDS);
     // counters (per part: walk entries, far tiles), the walk queue, the far-tile queue, the far tiles' open lanes
     const size_t far_off = (size_t)WALK_SHARDS * 16 + (size_t)WALK_SHARDS * tiles_per_shard * 64;
     const size_t mask_off = (far_off + (size_t)WALK_SHARDS * tiles_per_shard + 1) / 2 * 2;
-    const size_t queue_words = mask_off + 2 * (size_t)WALK_SHARDS * tiles_per_shard;
-    if (ctx->walk_queue.cap < queue_words * sizeof(unsigned)) {
-        ICPX_TRY(icpx_reserve(ctx, ctx->walk_queue, queue_words * sizeof(unsigned)));
-        ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->walk_queue.p, 0, WALK_SHARDS * 16 * sizeof(unsigned), ctx->stream));   // later passes: k_reduce_sums
-    }
     unsigned* qcount = ctx->walk_queue.as<unsigned>();
     unsigned* queue = qcount + WALK_SHARDS * 16;
     // k_icp_ball runs one wave per tile, one tile after the other: with few tiles (a scan of some ten thousand points) that is
