@@ -754,7 +754,7 @@ struct GoIcp::Search {
     std::unordered_map<CubeKey, ChildBounds, CubeKeyHash> ahead;   // bounds of the children of cubes not popped yet
 };
 
-// The eight children of a translation cube in the reference's order (src/GoIcp.cpp:391-401).
+// The eight children of a translation cube in the reference's order (src/GoIcp.cpp:378-390).
 static TransNode child_of(const TransNode& parent, int j) {
     TransNode node;
     node.w = (float)(parent.w / 2.0);

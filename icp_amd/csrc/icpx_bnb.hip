@@ -132,7 +132,7 @@ static __device__ __forceinline__ void bnb_fold(double* v, int lane, int o) {
 
 static __device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
 
-// Eight items per workgroup. The eight children of a translation cube (src/GoIcp.cpp:391-401) share the rotation, the
+// Eight items per workgroup. The eight children of a translation cube (src/GoIcp.cpp:378-390) share the rotation, the
 // level and the width, and each of their coordinates takes one of two values: the rotated point, its rotation
 // uncertainty and the six (coordinate, axis) cell computations are then done once for all eight, and only the voxel
 // lookup and the bound arithmetic per child. Which items form such a family is read off the items themselves (a
@@ -140,7 +140,7 @@ static __device__ __forceinline__ bool same_bits(float a, float b) { return __fl
 // multiple of eight, are evaluated one after the other as k_bnb_eval does. Every value is computed by the same float
 // operations on the same operands as there and added in the same order, so the bounds are the same bits.
 // PARENTS: `items` holds one record per family, the parent cube, and the eight children are formed here as the search
-// forms them (src/GoIcp.cpp:391-401: w' = w / 2, corner + (0 or 1) w' per axis, in float).
+// forms them (src/GoIcp.cpp:378-390: w' = w / 2, corner + (0 or 1) w' per axis, in float).
 template <bool BRICKS, bool PARENTS>
 __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
                                                    const icpx_bnb_item* __restrict__ items, int nitems, int nsplit, double* __restrict__ partials,

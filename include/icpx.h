@@ -216,7 +216,7 @@ int icpx_bnb_eval_async(icpx_ctx* ctx, const icpx_bnb_item* items, size_t nitems
 
 /* The search loop's form of the same evaluation: a record is a PARENT translation cube (x, y, z, w its corner and side,
  * R and level as above) and stands for its eight children in the order of GoIcp::innerBnB's child loop
- * (src/GoIcp.cpp:391-401: side w / 2, corner + (j & 1, j >> 1 & 1, j >> 2 & 1) * side, in float), so a batch goes up as an
+ * (src/GoIcp.cpp:378-390: side w / 2, corner + (j & 1, j >> 1 & 1, j >> 2 & 1) * side, in float), so a batch goes up as an
  * eighth of the records; the bounds are those icpx_bnb_eval gives for the eight children, bit for bit. Two batches can
  * be in flight, one per slot (0 or 1): icpx_bnb_submit copies the records, enqueues the work on the context's stream
  * and returns; icpx_bnb_collect waits for that slot's batch alone and hands out ub / lb, 8 * nparents doubles each

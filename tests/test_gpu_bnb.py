@@ -66,7 +66,7 @@ def test_residuals_match_oracle(gpu_ctx, oracle, bunny000, bun270):
 
 def _families(rng, nfam, widths):
     """Translation cubes as the search sends them: the eight children of `nfam` parents, in the reference's child order
-    (src/GoIcp.cpp:391-401: x = parent.x + (j & 1) w, y with bit 1, z with bit 2, all in float)."""
+    (src/GoIcp.cpp:378-390: x = parent.x + (j & 1) w, y with bit 1, z with bit 2, all in float)."""
     cubes = []
     for _ in range(nfam):
         px, py, pz = rng.uniform(-0.9, 0.4, 3).astype(np.float32)
@@ -162,7 +162,7 @@ def test_brick_copy_of_the_grid_far_from_the_surface(oracle, monkeypatch):
 
 
 def _children(parents_xyzw):
-    """The eight children of every parent cube in the reference's order and float arithmetic (src/GoIcp.cpp:391-401)."""
+    """The eight children of every parent cube in the reference's order and float arithmetic (src/GoIcp.cpp:378-390)."""
     out = []
     for x, y, z, w in parents_xyzw.astype(np.float32):
         cw = np.float32(w / 2.0)

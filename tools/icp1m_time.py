@@ -13,7 +13,7 @@ ctx = Context(0)
 t0 = time.perf_counter(); ctx.set_target(torch.from_numpy(tgt).cuda()); print("set_target s", round(time.perf_counter() - t0, 4))
 t0 = time.perf_counter(); ctx.set_source(torch.from_numpy(src).cuda()); print("set_source s", round(time.perf_counter() - t0, 4))
 T = np.eye(4); ms = []
-for it in range(40):
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     t0 = time.perf_counter(); s = ctx.icp_step(T); ms.append((time.perf_counter() - t0) * 1e3)
     T = kabsch_from_sums(s, n) @ T
 print("ms per pass:", [round(x, 3) for x in ms])
