@@ -86,6 +86,7 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
         if (v && sscanf(v, "%lld,%lld", &a, &b2) == 2 && a >= 0 && b2 >= 0) { ctx->icp_walk_all_tiles = (size_t)a; ctx->icp_ball_min_tiles = (size_t)b2; }
     }
     { const char* v = getenv("ICPX_CAND"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) { ctx->cand_enable = a != 0; if (a > 1) ctx->cand_max_entries = (size_t)a; } }
+    { const char* v = getenv("ICPX_BALL_FEW"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->icp_ball_few = (unsigned)a; }
     { const char* v = getenv("ICPX_BALL_MANY"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->icp_ball_many = (unsigned)a; }
     // ICPX_BNB_GROUP_MIN: bound batches of at least this many items go through the kernel that takes eight items per
     // workgroup (the tests set 0 and a huge value to compare the two kernels)

@@ -72,6 +72,7 @@ struct icpx_ctx {
     unsigned long long tile_counter_base = 0;   // their common value before the next launch
     size_t icp_walk_all_tiles = 1024;           // source clouds with fewer tiles skip the tile kernel: every point is walked (ICPX_ICP_TILES)
     size_t icp_ball_min_tiles = 2048;           // source clouds with at least this many tiles use the ball kernel for far tiles
+    unsigned icp_ball_few = 1024;               // with fewer far tiles than this the ball kernel hands their open lanes to k_icp_solo (ICPX_BALL_FEW)
     unsigned icp_ball_many = 8;                 // far tiles per wave of the ball kernel from which the large point / column caps apply (ICPX_BALL_MANY)
     DevBuf walk_queue;       // one ICP pass: the source points left to the pyramid walk, in 64 parts: a counter per part (16 words apart, zero between passes), then the parts' entries
     DevBuf partials;         // per-block partial sums

@@ -964,7 +964,7 @@ __attribute__((amdgpu_waves_per_eu(ICPX_BALL_WPE, ICPX_BALL_WPE)))
 __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
                                                               int* __restrict__ idx_out, int* __restrict__ seed, const unsigned* __restrict__ far_queue,
                                                               const unsigned long long* __restrict__ far_mask, unsigned* __restrict__ queue,
-                                                              unsigned* __restrict__ qcount, unsigned tiles_per_shard, unsigned many_factor) {
+                                                              unsigned* __restrict__ qcount, unsigned tiles_per_shard, unsigned many_factor, unsigned few_tiles) {
     __shared__ float sw_xyz[TILE_WAVES][4][TILE_CAP + 8];
     __shared__ int sw_first[TILE_WAVES][TILE_COLS];
     __shared__ int sw_pre[TILE_WAVES][TILE_COLS + 4];
@@ -990,6 +990,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
     // from its target, whose balls hold four times the points of a million-point cloud's) they average out, and the walk
     // would take several times longer for them.
     const bool many = items >= many_factor * gridDim.x * TILE_WAVES;
+    unsigned total_tiles = my_count;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total_tiles += __shfl_xor(total_tiles, o);
+    const bool few = total_tiles < few_tiles;
     const int max_pts = many ? 16 * BALL_MAX_PTS : BALL_MAX_PTS, max_cols = many ? 4 * BALL_MAX_COLS : BALL_MAX_COLS;
 
     // (letting a wave whose run is used up go on with the other XCDs' runs moved time between the passes and saved none)
@@ -998,25 +1002,29 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
         if (lane == 0) {
             // a look before the addition: additions to one word go one after the other, and with little to do (the converged
             // passes) the kernel would last as long as its waves' additions take
-#ifdef ICPX_BALL_ONE_COUNTER
-            taken = __hip_atomic_load(&qcount[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (taken < items) taken = atomicAdd(&qcount[2], 1u);
-        }
-        taken = __shfl(taken, 0);
-        const unsigned item = taken;
-        if (item >= items) break;       // uniform
-#else
             taken = __hip_atomic_load(&qcount[group * 16 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (taken < per_group) taken = atomicAdd(&qcount[group * 16 + 2], 1u);
         }
         taken = __shfl(taken, 0);
         const unsigned item = group * per_group + taken;
         if (taken >= per_group || item >= items) break;       // uniform
-#endif
         const unsigned shard = item / most, e = item % most;
         if (e >= (unsigned)__shfl((int)my_count, (int)shard)) continue;
         const size_t tile = far_queue[(size_t)shard * tiles_per_shard + e], base = tile * 64;
         const unsigned long long open = far_mask[tile];
+        if (few) {
+            // Few far tiles (the later passes): a tile is a chain of dependent steps for one wave, 150 to 300 us whatever
+            // else the GPU does, and with fewer tiles than waves that is what the kernel lasts. The open lanes go to
+            // k_icp_solo instead, a wave per query, whose hundreds of short jobs fill the GPU.
+            if ((open >> lane) & 1ull) {
+                unsigned at = 0;
+                const unsigned first = (unsigned)__ffsll((long long)open) - 1u;
+                if (lane == (int)first) at = atomicAdd(&qcount[shard * 16 + 3], (unsigned)__popcll(open));
+                at = __shfl(at, (int)first);
+                queue[(size_t)shard * tiles_per_shard * 64 + (size_t)tiles_per_shard * 64 - 1 - (at + __popcll(open & ((1ull << lane) - 1ull)))] = (unsigned)(base + lane);
+            }
+            continue;
+        }
 #ifdef ICPX_NN_STATS
         unsigned long long t_last = wall_clock64();
         const unsigned long long t_tile = t_last;
@@ -1320,7 +1328,12 @@ __global__ __launch_bounds__(256) void k_icp_solo(GridView g, const float4* __re
         const float4 s = src[i];
         double p[3];
         icp_transform(T, s, p);
-        Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);     // the same in every lane; present, or the query would not be here
+        Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);     // the same in every lane
+        if (b.pos < 0) cand_lookup(g, p[0], p[1], p[2], b);
+        if (b.pos < 0) {                                            // no candidate anywhere: an empty target
+            if (lane == 0) { seed[i] = -1; if (idx_out) idx_out[__float_as_int(s.w)] = b.idx; }
+            continue;
+        }
         const QueryF f(p[0], p[1], p[2], (double)h);
         const float r = (float)__dsqrt_rn(b.d2);
         const float Rw = r * (1.f + 1e-5f) + 0.02f * h, R2 = Rw * Rw;
@@ -1358,6 +1371,8 @@ __global__ __launch_bounds__(256) void k_icp_solo(GridView g, const float4* __re
 #pragma unroll
             for (int a = 0; a < AHEAD; a++)
                 for (int k = firsts[a]; k < ends[a]; k++) {
+                    // (asking for the first four points of every column together, before knowing which columns hold any, made
+                    // the kernel a fifth slower: most chords are empty)
                     const float4 t = g.pts[k];
                     const float fx = qx - t.x, fy = qy - t.y, fz = qz - t.z;
                     const float sf = (fx * fx + fy * fy) + fz * fz;
@@ -1808,7 +1823,7 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
                        far_queue, far_mask);
     if (use_ball)
         hipLaunchKernelGGL(k_icp_ball, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
-                           ctx->nn_seed.as<int>(), far_queue, far_mask, queue, qcount, tiles_per_shard, ctx->icp_ball_many);
+                           ctx->nn_seed.as<int>(), far_queue, far_mask, queue, qcount, tiles_per_shard, ctx->icp_ball_many, ctx->icp_ball_few);
     if (!walk_all)
         hipLaunchKernelGGL(k_icp_solo, dim3((unsigned)std::min<size_t>((ctx->ns + 255) / 256, (size_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
                            queue, qcount, tiles_per_shard, idx_dev, ctx->nn_seed.as<int>());
