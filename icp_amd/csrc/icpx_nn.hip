@@ -996,18 +996,28 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
     const bool few = total_tiles < few_tiles;
     const int max_pts = many ? 16 * BALL_MAX_PTS : BALL_MAX_PTS, max_cols = many ? 4 * BALL_MAX_COLS : BALL_MAX_COLS;
 
-    // (letting a wave whose run is used up go on with the other XCDs' runs moved time between the passes and saved none)
+    // A wave whose XCD's run is used up goes on with the next XCD's (and so on round the eight): the runs differ in work,
+    // on the 16 M pair by a factor of 2.5 between the first XCD to finish and the last (wave end times from 45 to 121 ms
+    // in the first pass); the tiles taken that way come out of another L2, but only at the end of the kernel.
+#ifndef ICPX_BALL_STEAL
+#define ICPX_BALL_STEAL 1
+#endif
+    unsigned gsel = group, hops = 0;
     for (;;) {
         unsigned taken = 0;
         if (lane == 0) {
             // a look before the addition: additions to one word go one after the other, and with little to do (the converged
             // passes) the kernel would last as long as its waves' additions take
-            taken = __hip_atomic_load(&qcount[group * 16 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (taken < per_group) taken = atomicAdd(&qcount[group * 16 + 2], 1u);
+            taken = __hip_atomic_load(&qcount[gsel * 16 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (taken < per_group) taken = atomicAdd(&qcount[gsel * 16 + 2], 1u);
         }
         taken = __shfl(taken, 0);
-        const unsigned item = group * per_group + taken;
-        if (taken >= per_group || item >= items) break;       // uniform
+        const unsigned item = gsel * per_group + taken;
+        if (taken >= per_group || item >= items) {            // uniform
+            if (!ICPX_BALL_STEAL || ++hops >= 8) break;
+            gsel = (gsel + 1) & 7u;
+            continue;
+        }
         const unsigned shard = item / most, e = item % most;
         if (e >= (unsigned)__shfl((int)my_count, (int)shard)) continue;
         const size_t tile = far_queue[(size_t)shard * tiles_per_shard + e], base = tile * 64;
