@@ -403,7 +403,29 @@ __device__ __forceinline__ Best best_seed(const GridView& g, const int* __restri
     return b;
 }
 
-__device__ __forceinline__ void cand_lookup(const GridView& g, double qx, double qy, double qz, Best& b);   // the candidate table, below
+// The same for the kernels of an ICP pass, which keep the pair as a copy of the target point itself (x, y, z, index bits;
+// index bits < 0: none) by source point: one coalesced read where the position costs a read and then a gather that the
+// whole tile waits for. Such a candidate has no position: Best::pos is PAIR_POS. `point` receives the copy.
+constexpr int PAIR_POS = 0x7ffffffe;
+__device__ __forceinline__ Best best_pair(const float4* __restrict__ pair, size_t i, double qx, double qy, double qz, float4& point) {
+    Best b;
+    b.init();
+    const float4 t = pair[i];
+    point = t;
+    if (__float_as_int(t.w) >= 0) {
+        const double dx = qx - (double)t.x, dy = qy - (double)t.y, dz = qz - (double)t.z;
+        b.d2 = (dx * dx + dy * dy) + dz * dz;
+        b.idx = __float_as_int(t.w);
+        b.pos = PAIR_POS;
+    }
+    return b;
+}
+// Best::offer that also keeps the point of the best
+__device__ __forceinline__ void offer_point(Best& b, float4& point, double d, const float4& t, int at) {
+    if (d < b.d2 || (d == b.d2 && __float_as_int(t.w) < b.idx)) { b.d2 = d; b.idx = __float_as_int(t.w); b.pos = at; point = t; }
+}
+
+__device__ __forceinline__ void cand_lookup(const GridView& g, double qx, double qy, double qz, Best& b, float4* point = nullptr);   // the candidate table, below
 
 // K nearest target points of every query, ascending by (squared distance, index); slots beyond the number
 // of target points get index -1 and an infinite distance.
@@ -509,7 +531,7 @@ __global__ void k_cand_flood(GridView g, const int* __restrict__ in, int* __rest
 }
 
 // The table's candidate for q, offered to b with its exact distance.
-__device__ __forceinline__ void cand_lookup(const GridView& g, double qx, double qy, double qz, Best& b) {
+__device__ __forceinline__ void cand_lookup(const GridView& g, double qx, double qy, double qz, Best& b, float4* point) {
     if (!g.cand) return;
     const int i = cell_coord((float)qx, g.minx, g.inv, g.dx) >> g.cshift, j = cell_coord((float)qy, g.miny, g.inv, g.dy) >> g.cshift,
               k = cell_coord((float)qz, g.minz, g.inv, g.dz) >> g.cshift;
@@ -517,13 +539,15 @@ __device__ __forceinline__ void cand_lookup(const GridView& g, double qx, double
     if (at < 0) return;
     const float4 t = g.pts[at];
     const double dx = qx - (double)t.x, dy = qy - (double)t.y, dz = qz - (double)t.z;
-    b.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(t.w), at);
+    const double d = (dx * dx + dy * dy) + dz * dz;
+    if (point) offer_point(b, *point, d, t, at);
+    else b.offer(d, __float_as_int(t.w), at);
 }
 
 struct Mat34 { double m[12]; };
 
 // ---- one ICP pass, a wave per tile of 64 source points ------------------------------------------------------
-// p = T * [src;1] (multiply then add, k = 0..3 from a zero accumulator) and its nearest target point q, left in seed[]
+// p = T * [src;1] (multiply then add, k = 0..3 from a zero accumulator) and its nearest target point q, left in pair[]
 // as a position in the sorted target points; k_icp_sums then forms the sums {p, q, p q^T, |p-q|^2}.
 //
 // The source cloud is in Morton order, so the 64 points of a wave fall into a few neighbouring cells. Every lane names
@@ -642,7 +666,7 @@ __device__ __forceinline__ size_t icp_tile_of(int tt, int tiles_per_wave) {
 // (round-robin dispatch) and such a group shares one contiguous eighth of the tiles, taken in order through one of
 // eight counters (64-bit, one cache line each, never reset: the host passes the value they had before this launch),
 // so waves that are resident together work on neighbouring tiles, whose cell columns overlap, out of one L2. One
-// counter takes about 88 additions per microsecond; an eighth of the tiles of a million points needs 2 000. seed (in / out): per source position, the position of its pair in the sorted target points.
+// counter takes about 88 additions per microsecond; an eighth of the tiles of a million points needs 2 000. pair (in / out): per source position, a copy of the target point it is paired with (see best_pair).
 #ifdef ICPX_NN_STATS
 __device__ unsigned long long g_nn_stats[16];
 __device__ unsigned long long g_ball_t[8];   // wall-clock ticks of k_icp_ball by phase: candidates, geometry, columns, staging, compare, resolve, whole tile
@@ -679,7 +703,7 @@ __device__ __forceinline__ void icp_enqueue_open(unsigned long long pend, bool h
 }
 
 __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
-                                                              int* __restrict__ idx_out, int* __restrict__ seed, size_t tiles_per_group,
+                                                              int* __restrict__ idx_out, float4* __restrict__ pair, size_t tiles_per_group,
                                                               unsigned long long* __restrict__ counters, unsigned long long counter_base,
                                                               unsigned* __restrict__ queue, unsigned* __restrict__ qcount, unsigned tiles_per_shard,
                                                               unsigned* __restrict__ far_queue, unsigned long long* __restrict__ far_mask) {
@@ -715,8 +739,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
         const float4 s = src[i];
         double p[3];
         icp_transform(T, s, p);
-        Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);
-        if (b.pos < 0) cand_lookup(g, p[0], p[1], p[2], b);      // no previous pair (a first pass): the table's candidate
+        float4 bt;
+        Best b = best_pair(pair, i, p[0], p[1], p[2], bt);
+        if (b.pos < 0) cand_lookup(g, p[0], p[1], p[2], b, &bt);      // no previous pair (a first pass): the table's candidate
         const int cx = cell_coord((float)p[0], g.minx, g.inv, g.dx), cy = cell_coord((float)p[1], g.miny, g.inv, g.dy),
                   cz = cell_coord((float)p[2], g.minz, g.inv, g.dz);
         const double margin = 1e-3 * h + 1e-6 * (fabs(p[0]) + fabs(p[1]) + fabs(p[2]));
@@ -880,7 +905,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
                 const double tn = (double)__fsqrt_rn(wmax) * (1.0 + 1e-6), qn = __dsqrt_rn(qb2);
                 const double E = 10.0 * 0x1p-24 * (tn * tn + 2.0 * qn * tn) + 1e-30;
                 ambiguous = !((double)u2 > (d - qb2) + E);
-                b.offer(d, __float_as_int(t.w), at);
+                offer_point(b, bt, d, t, at);
             }
         }
         const bool settled = staged && !ambiguous && (near_lane || outside > b.d2);
@@ -906,7 +931,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const 
             icp_enqueue_open(pend, b.pos >= 0, b.d2, g.h, tile / tiles_per_shard, tiles_per_shard, queue, qcount, (unsigned)i, lane);
         }
         if (!valid) continue;
-        seed[i] = b.pos;                     // for a queued lane: the candidate its walk starts from
+        if (b.pos != PAIR_POS) pair[i] = bt; // for a queued lane: the candidate its walk starts from
         if (settled && idx_out) idx_out[__float_as_int(s.w)] = b.idx;
     }
 #ifdef ICPX_NN_STATS
@@ -962,7 +987,7 @@ __device__ __forceinline__ void greedy_candidate(const GridView& g, const unsign
 __attribute__((amdgpu_waves_per_eu(ICPX_BALL_WPE, ICPX_BALL_WPE)))
 #endif
 __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
-                                                              int* __restrict__ idx_out, int* __restrict__ seed, const unsigned* __restrict__ far_queue,
+                                                              int* __restrict__ idx_out, float4* __restrict__ pair, const unsigned* __restrict__ far_queue,
                                                               const unsigned long long* __restrict__ far_mask, unsigned* __restrict__ queue,
                                                               unsigned* __restrict__ qcount, unsigned tiles_per_shard, unsigned many_factor, unsigned few_tiles) {
     __shared__ float sw_xyz[TILE_WAVES][4][TILE_CAP + 8];
@@ -1044,20 +1069,24 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
         const float4 s = src[i];
         double p[3];
         icp_transform(T, s, p);
-        Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);
-        if (mine && b.pos < 0) cand_lookup(g, p[0], p[1], p[2], b);
+        float4 bt;
+        Best b = best_pair(pair, i, p[0], p[1], p[2], bt);
+        if (mine && b.pos < 0) cand_lookup(g, p[0], p[1], p[2], b, &bt);
         const bool unpaired = __any(mine && b.pos < 0);          // no table (it is switched off): a greedy descent, then the neighbours' finds
-        if (mine && b.pos < 0) greedy_candidate(g, s_loff, p[0], p[1], p[2], b);
+        if (mine && b.pos < 0) {
+            greedy_candidate(g, s_loff, p[0], p[1], p[2], b);
+            if (b.pos >= 0) bt = g.pts[b.pos];
+        }
         // The lanes' queries are neighbours: try each other's candidates. Only where some lane came without a previous pair
         // (the first pass): what a greedy descent finds can be far off, a previous pair hardly is, and the six dependent
         // reads cost a fifth of a tile's time.
 #pragma unroll
         for (int o = 1; unpaired && o < 64; o <<= 1) {
             const int other = __shfl_xor(b.pos, o);
-            if (mine && other >= 0 && other != b.pos) {
+            if (mine && other >= 0 && other != PAIR_POS && other != b.pos) {       // (a lane's previous pair is not passed on)
                 const float4 t = g.pts[other];
                 const double dx = p[0] - (double)t.x, dy = p[1] - (double)t.y, dz = p[2] - (double)t.z;
-                b.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(t.w), other);
+                offer_point(b, bt, (dx * dx + dy * dy) + dz * dz, t, other);
             }
         }
         BALL_T(0);
@@ -1244,7 +1273,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
                 // every other staged point B has |q - B|^2 >= u2 + |q - c|^2 - E (see above): strictly farther when that exceeds d
                 const double far_most = (double)Rw + 3.5 * (double)h + (double)spread * (1.0 + 1e-5), E = 10.0 * 0x1p-24 * far_most * far_most;
                 settled = (double)u2 > (d - qb2) + E;
-                b.offer(d, __float_as_int(t.w), best_at);
+                offer_point(b, bt, d, t, best_at);
             }
         }
         const unsigned long long pend = __ballot(mine && !settled);
@@ -1257,19 +1286,19 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
 #endif
         if (pend) icp_enqueue_open(pend, b.pos >= 0, b.d2, g.h, shard, tiles_per_shard, queue, qcount, (unsigned)i, lane);
         if (!mine) continue;
-        seed[i] = b.pos;
+        if (b.pos != PAIR_POS) pair[i] = bt;
         if (settled && idx_out) idx_out[__float_as_int(s.w)] = b.idx;
     }
 }
 
-// The queued source points: eight lanes each, the pyramid walk of nn_search8 from the candidate in seed[]. The work is
+// The queued source points: eight lanes each, the pyramid walk of nn_search8 from the candidate in pair[]. The work is
 // cut into groups of NN_OCTETS consecutive entries of one part of the queue (see k_icp_tile), numbered part by part,
 // and dealt to the workgroups in turn: the workgroups that are resident together work on one stretch of the cloud
 // (whose cells and pyramid nodes then stay in L2: spreading them over the whole cloud cost a third more time), and
 // over its life every workgroup gets groups from all over the cloud (how long a walk takes depends on where the query is).
 __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __restrict__ src, Mat34 T, size_t nt, const unsigned* __restrict__ queue,
                                                   const unsigned* __restrict__ qcount, unsigned tiles_per_shard, int* __restrict__ idx_out,
-                                                  int* __restrict__ seed, size_t n_all) {
+                                                  float4* __restrict__ pair, size_t n_all) {
     __shared__ unsigned snode[NN_STACK * NN_OCTETS];
     __shared__ float slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
@@ -1283,11 +1312,13 @@ __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __re
             const float4 s = src[i];
             double p[3];
             icp_transform(T, s, p);
-            Best b0 = best_seed(g, seed, i, nt, p[0], p[1], p[2]);
-            if (b0.pos < 0) cand_lookup(g, p[0], p[1], p[2], b0);
+            float4 bt;
+            Best b0 = best_pair(pair, i, p[0], p[1], p[2], bt);
+            if (b0.pos < 0) cand_lookup(g, p[0], p[1], p[2], b0, &bt);
             const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, b0);
             if ((threadIdx.x & 7) != 0) continue;
-            seed[i] = b.pos;
+            if (b.pos != b0.pos) bt = g.pts[b.pos];           // (the walk only offers points by their position)
+            if (b.pos != PAIR_POS) pair[i] = bt;
             if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
         }
         return;
@@ -1305,9 +1336,11 @@ __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __re
         const float4 s = src[i];
         double p[3];
         icp_transform(T, s, p);
-        const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, best_seed(g, seed, i, nt, p[0], p[1], p[2]));
+        float4 bt;
+        const Best b0 = best_pair(pair, i, p[0], p[1], p[2], bt);
+        const Best b = nn_search8(g, p[0], p[1], p[2], snode, slb, (int)(threadIdx.x >> 3), NN_OCTETS, s_loff, b0);
         if ((threadIdx.x & 7) != 0) continue;
-        seed[i] = b.pos;
+        if (b.pos != b0.pos) pair[i] = g.pts[b.pos];
         if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
     }
 }
@@ -1321,7 +1354,7 @@ __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __re
 // results are reduced by (distance, index). Every point as near as the candidate lies in the ball, so the result is the
 // exact nearest point with the lowest index, as from the walk.
 __global__ __launch_bounds__(256) void k_icp_solo(GridView g, const float4* __restrict__ src, Mat34 T, size_t nt, const unsigned* __restrict__ queue,
-                                                  const unsigned* __restrict__ qcount, unsigned tiles_per_shard, int* __restrict__ idx_out, int* __restrict__ seed) {
+                                                  const unsigned* __restrict__ qcount, unsigned tiles_per_shard, int* __restrict__ idx_out, float4* __restrict__ pair) {
     __shared__ unsigned s_count[WALK_SHARDS];
     if (threadIdx.x < WALK_SHARDS) s_count[threadIdx.x] = qcount[threadIdx.x * 16 + 3];
     __syncthreads();
@@ -1338,12 +1371,14 @@ __global__ __launch_bounds__(256) void k_icp_solo(GridView g, const float4* __re
         const float4 s = src[i];
         double p[3];
         icp_transform(T, s, p);
-        Best b = best_seed(g, seed, i, nt, p[0], p[1], p[2]);     // the same in every lane
-        if (b.pos < 0) cand_lookup(g, p[0], p[1], p[2], b);
-        if (b.pos < 0) {                                            // no candidate anywhere: an empty target
-            if (lane == 0) { seed[i] = -1; if (idx_out) idx_out[__float_as_int(s.w)] = b.idx; }
+        float4 bt;
+        Best b = best_pair(pair, i, p[0], p[1], p[2], bt);        // the same in every lane
+        if (b.pos < 0) cand_lookup(g, p[0], p[1], p[2], b, &bt);
+        if (b.pos < 0) {                                            // no candidate anywhere: an empty target (the pair stays "none")
+            if (lane == 0 && idx_out) idx_out[__float_as_int(s.w)] = b.idx;
             continue;
         }
+        const int pos0 = b.pos;
         const QueryF f(p[0], p[1], p[2], (double)h);
         const float r = (float)__dsqrt_rn(b.d2);
         const float Rw = r * (1.f + 1e-5f) + 0.02f * h, R2 = Rw * Rw;
@@ -1400,17 +1435,18 @@ __global__ __launch_bounds__(256) void k_icp_solo(GridView g, const float4* __re
             if (d < b.d2 || (d == b.d2 && id < b.idx)) { b.d2 = d; b.idx = id; b.pos = at; }
         }
         if (lane == 0) {
-            seed[i] = b.pos;
+            if (b.pos != pos0) bt = g.pts[b.pos];               // (the scan offers points by their position)
+            if (b.pos != PAIR_POS) pair[i] = bt;
             if (idx_out) idx_out[__float_as_int(s.w)] = b.idx;
         }
     }
 }
 
-// Block-partial sums {p, q, p q^T, |p-q|^2} over the pairs in seed[]: lane l of a block adds the terms of point l of
+// Block-partial sums {p, q, p q^T, |p-q|^2} over the pairs in pair[]: lane l of a block adds the terms of point l of
 // its tiles in tile order and the lanes are summed by a fixed butterfly, so the sums depend on the pairs alone (not on
 // which points were settled by k_icp_tile and which by the walk, which varies with the previous pass).
 __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_sums(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
-                                                 const int* __restrict__ seed, int tiles_per_block, double* __restrict__ partials) {
+                                                 const float4* __restrict__ pair, int tiles_per_block, double* __restrict__ partials) {
     const int lane = (int)(threadIdx.x & 63);
     double acc[ICPX_NSUMS];
 #pragma unroll
@@ -1420,9 +1456,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_sums(GridView g, const 
         if (i >= n) continue;
         double p[3];
         icp_transform(T, src[i], p);
-        const int at = seed[i];
+        float4 q = pair[i];
         // no candidate at all (a NaN in T): the sums are NaN anyway
-        const float4 q = at >= 0 && (size_t)at < nt ? g.pts[at] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (__float_as_int(q.w) < 0) q = make_float4(0.f, 0.f, 0.f, 0.f);
         const double dx = p[0] - (double)q.x, dy = p[1] - (double)q.y, dz = p[2] - (double)q.z;
         icp_accumulate(acc, p, q, (dx * dx + dy * dy) + dz * dz);
     }
@@ -1759,6 +1795,8 @@ extern "C" int icpx_set_source(icpx_ctx* ctx, const float* xyz, size_t n, size_t
     // correspondences of the last pass, by sorted position (-1 = none): the next pass starts its search from them
     ICPX_TRY(icpx_reserve(ctx, ctx->nn_seed, n * sizeof(int)));
     ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->nn_seed.p, 0xff, n * sizeof(int), ctx->stream));
+    ICPX_TRY(icpx_reserve(ctx, ctx->nn_pair, n * sizeof(float4)));
+    ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->nn_pair.p, 0xff, n * sizeof(float4), ctx->stream));
     ctx->ns = n;
     ICPX_TRY(icp_step_reserve(ctx));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1829,22 +1867,22 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     const bool walk_all = tiles < ctx->icp_walk_all_tiles;
     if (!walk_all)
     hipLaunchKernelGGL(k_icp_tile, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
-                       ctx->nn_seed.as<int>(), tiles_per_group, ctx->tile_counters.as<unsigned long long>(), counter_base, queue, qcount, tiles_per_shard,
+                       ctx->nn_pair.as<float4>(), tiles_per_group, ctx->tile_counters.as<unsigned long long>(), counter_base, queue, qcount, tiles_per_shard,
                        far_queue, far_mask);
     if (use_ball)
         hipLaunchKernelGGL(k_icp_ball, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
-                           ctx->nn_seed.as<int>(), far_queue, far_mask, queue, qcount, tiles_per_shard, ctx->icp_ball_many, ctx->icp_ball_few);
+                           ctx->nn_pair.as<float4>(), far_queue, far_mask, queue, qcount, tiles_per_shard, ctx->icp_ball_many, ctx->icp_ball_few);
     if (!walk_all)
         hipLaunchKernelGGL(k_icp_solo, dim3((unsigned)std::min<size_t>((ctx->ns + 255) / 256, (size_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
-                           queue, qcount, tiles_per_shard, idx_dev, ctx->nn_seed.as<int>());
+                           queue, qcount, tiles_per_shard, idx_dev, ctx->nn_pair.as<float4>());
     // (what is left to the walk when the tile kernels ran: queries without any candidate, or absurdly far from theirs; the
     // grid is small because launching two thousand workgroups that find nothing to do costs 25 us a pass)
     const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, (size_t)ctx->num_cus * 2 / WALK_SHARDS) * WALK_SHARDS);
     const unsigned all_blocks = (unsigned)std::min<size_t>((ctx->ns + NN_OCTETS - 1) / NN_OCTETS, (size_t)ctx->num_cus * 8);
     hipLaunchKernelGGL(k_icp_walk, dim3(walk_all ? all_blocks : std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
-                       queue, qcount, tiles_per_shard, idx_dev, ctx->nn_seed.as<int>(), walk_all ? ctx->ns : (size_t)0);
+                       queue, qcount, tiles_per_shard, idx_dev, ctx->nn_pair.as<float4>(), walk_all ? ctx->ns : (size_t)0);
     hipLaunchKernelGGL(k_icp_sums, dim3(sblocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt,
-                       ctx->nn_seed.as<int>(), tiles_per_sblock, part);
+                       ctx->nn_pair.as<float4>(), tiles_per_sblock, part);
     hipLaunchKernelGGL(k_reduce_sums, dim3(ICPX_NSUMS), dim3(256), 0, ctx->stream, part, swaves, sums_dev, qcount, WALK_SHARDS);
 #ifdef ICPX_NN_STATS
     {
