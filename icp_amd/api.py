@@ -254,6 +254,23 @@ class Context:
         count = n - first if count is None else count
         self._ck(self._lib.icpx_bnb_eval_async(self._h, C.cast(items, C.c_void_p), n, first, count, _dev(out_dev, self)))
 
+    def bnb_search(self, Rs, levels, opt_errors, cubes, sse_thresh):
+        """icpx_bnb_search_run: one inner search per (rotation, level, starting error, starting cube), run on the device to the
+        end. Returns (opt_error float32[n], have_best bool[n], best float32[n, 4], cubes int[n], status int[n], steps)."""
+        from .lib import BnbFound, BnbSearch
+        n = len(levels)
+        arr = (BnbSearch * n)()
+        for i in range(n):
+            arr[i].R[:] = [float(v) for v in np.asarray(Rs[i], np.float32).reshape(9)]
+            arr[i].level = int(levels[i]); arr[i].opt_error = float(opt_errors[i])
+            arr[i].cube[:] = [float(v) for v in np.asarray(cubes[i], np.float32).reshape(4)]
+        out = (BnbFound * n)()
+        steps = C.c_longlong(0)
+        self._ck(self._lib.icpx_bnb_search_run(self._h, C.cast(arr, C.c_void_p), n, C.c_float(sse_thresh), C.cast(out, C.c_void_p), C.byref(steps)))
+        return (np.array([o.opt_error for o in out], np.float32), np.array([bool(o.have_best) for o in out]),
+                np.array([list(o.best) for o in out], np.float32).reshape(n, 4), np.array([o.cubes for o in out]),
+                np.array([o.status for o in out]), steps.value)
+
     def bnb_submit(self, slot, parents, first=0, count=None, out_dev=None):
         """icpx_bnb_submit: the eight children of every parent cube in `parents` (make_items records), as batch `slot`."""
         n = len(parents)

@@ -661,7 +661,8 @@ struct Stopwatch {
     double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     ~Stopwatch() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
-double g_t_build = 0, g_t_take = 0, g_t_icp = 0;   // ICPX_GOICP_VERBOSE: host time putting batches together, digesting bounds, in runICP
+double g_t_build = 0, g_t_take = 0, g_t_icp = 0;
+long long g_pops_hist[12] = {0}, g_longest_sum = 0, g_run_calls = 0, g_longest_max = 0;   // ICPX_GOICP_VERBOSE: cubes popped per search (log2 buckets), longest search of each run_searches call   // ICPX_GOICP_VERBOSE: host time putting batches together, digesting bounds, in runICP
 }  // namespace
 
 // Evaluates a batch of cubes; with several ranks each one evaluates a contiguous slice and the slices
@@ -750,6 +751,7 @@ struct GoIcp::Search {
     float optErrorT;
     TransNode best;
     bool have_best = false, done = false;
+    int pops = 0;              // cubes taken off the queue so far
     std::vector<TransNode> pending;   // parents whose 8 children are in the batch, in evaluation order
     std::unordered_map<CubeKey, ChildBounds, CubeKeyHash> ahead;   // bounds of the children of cubes not popped yet
 };
@@ -868,12 +870,60 @@ void GoIcp::collect_parents(int slot, std::vector<float>& ub, std::vector<float>
     for (size_t k = 0; k < n; k++) { ub[k] = (float)slot_d[k]; lb[k] = (float)slot_d[n + k]; }
 }
 
+// The searches as one call of icpx_bnb_search_run. Searches the device could not finish (a queue beyond its capacity, too
+// many steps) are reset to their start and handed back in `left`.
+bool GoIcp::run_searches_device(const std::vector<Search*>& ss, std::vector<Search*>& left) {
+    std::vector<icpx_bnb_search> in(ss.size());
+    std::vector<icpx_bnb_found> out(ss.size());
+    for (size_t i = 0; i < ss.size(); i++) {
+        const Search& s = *ss[i];
+        if (s.que.size() != 1 || s.pops != 0 || s.done) return false;      // not at its start: the host loop carries on
+        std::memcpy(in[i].R, s.R, sizeof s.R);
+        in[i].level = s.level;
+        in[i].opt_error = s.optErrorT;
+        const TransNode& t = s.que.top();
+        in[i].cube[0] = t.x; in[i].cube[1] = t.y; in[i].cube[2] = t.z; in[i].cube[3] = t.w;
+    }
+    long long steps = 0;
+    {
+        Stopwatch watch{eval_seconds};
+        dev->check(icpx_bnb_search_run(dev->ctx(), in.data(), in.size(), sseThresh, out.data(), &steps));
+    }
+    search_steps += steps;
+    launches += 2 * steps;
+    for (size_t i = 0; i < ss.size(); i++) {
+        Search& s = *ss[i];
+        inner_evals += 8LL * out[i].cubes;
+        if (out[i].status != 0) { left.push_back(&s); continue; }
+        s.optErrorT = out[i].opt_error;
+        s.have_best = out[i].have_best != 0;
+        if (s.have_best) { s.best.x = out[i].best[0]; s.best.y = out[i].best[1]; s.best.z = out[i].best[2]; s.best.w = out[i].best[3]; s.best.lb = s.best.ub = 0; }
+        s.pops = out[i].cubes;
+        s.done = true;
+        while (!s.que.empty()) s.que.pop();
+    }
+    return true;
+}
+
 void GoIcp::run_searches(const std::vector<Search*>& ss) {
+    if (ss.empty()) return;
+    if (device_search && frontier_width == 1 && !parity_sums && !shared_launches()) {
+        std::vector<Search*> left;
+        if (run_searches_device(ss, left)) {
+            if (!left.empty()) run_searches_host(left);
+            return;
+        }
+    }
+    run_searches_host(ss);
+}
+
+void GoIcp::run_searches_host(const std::vector<Search*>& ss) {
     const int width = std::max(1, frontier_width);
     const int ahead_base = width == 1 ? std::max(0, lookahead) : 0;
     std::vector<size_t> cand;    // look-ahead: heap positions still to visit
     // Takes the children's bounds of one popped parent in the reference's order (src/GoIcp.cpp:403-452).
     auto take = [&](Search& s, const TransNode& parent, const float* u8, const float* l8) {
+        s.pops++;
         for (int j = 0; j < 8 && !s.done; j++) {
             TransNode node = child_of(parent, j);
             const float u = u8[j], l = l8[j];
@@ -980,6 +1030,14 @@ void GoIcp::run_searches(const std::vector<Search*>& ss) {
             build(groups[g]);
             if (!groups[g].parents.empty()) { submit_parents(g, groups[g].parents); groups[g].in_flight = true; }
         }
+    int longest = 0;
+    for (const Search* s : ss) {
+        int b = 0;
+        while ((1 << b) < s->pops && b < 11) b++;
+        g_pops_hist[b]++;
+        longest = std::max(longest, s->pops);
+    }
+    g_longest_sum += longest; g_run_calls++; g_longest_max = std::max<long long>(g_longest_max, longest);
 }
 
 float GoIcp::innerBnB(float* maxDistL, TransNode* transOut) {
@@ -1016,7 +1074,7 @@ static bool rotation_of(float v1, float v2, float v3, float R[9]) {
 }
 
 float GoIcp::OuterBnB() {
-    rot_pops = inner_evals = launches = collectives = 0;
+    rot_pops = inner_evals = launches = collectives = search_steps = 0;
     eval_seconds = 0;
 
     // initial error: identity pose, sequential float sum (src/GoIcp.cpp:159-172)
@@ -1225,6 +1283,12 @@ float GoIcp::OuterBnB() {
     }
     if (std::getenv("ICPX_GOICP_VERBOSE"))
         std::fprintf(stderr, "GoIcp: %lld launches, %lld bound evaluations, %.3f s inside the batches; build %.3f take %.3f icp %.3f\n", launches, inner_evals, eval_seconds, g_t_build, g_t_take, g_t_icp), g_t_build = g_t_take = g_t_icp = 0;
+    if (std::getenv("ICPX_GOICP_VERBOSE")) {
+        std::fprintf(stderr, "GoIcp: %lld sets of searches, longest search of a set: %lld cubes summed over the sets, %lld at most; searches by cubes popped (<=1, 2, <=4, ...):", g_run_calls, g_longest_sum, g_longest_max);
+        for (long long& h : g_pops_hist) { std::fprintf(stderr, " %lld", h); h = 0; }
+        std::fprintf(stderr, "\n");
+        g_run_calls = g_longest_sum = g_longest_max = 0;
+    }
     return optError;
 }
 
@@ -1475,6 +1539,7 @@ int icpxh_goicp_exact_residuals(void* p, int on) { ((HGo*)p)->go->exact_residual
 int icpxh_goicp_shard_cubes(void* p, int on) { ((HGo*)p)->go->shard_cubes = on != 0; return 0; }
 int icpxh_goicp_pipeline(void* p, int on) { ((HGo*)p)->go->pipeline = on != 0; return 0; }
 int icpxh_goicp_tail_lookahead(void* p, int on) { ((HGo*)p)->go->tail_lookahead = on != 0; return 0; }
+int icpxh_goicp_device_search(void* p, int on) { ((HGo*)p)->go->device_search = on != 0; return 0; }
 // Device-side collective: allreduce_dev sums n doubles at a device address inside [dev_buffer, dev_buffer + capacity) over
 // the ranks, in place, on the stream given here (which the context then uses for everything).
 int icpxh_goicp_set_collective_dev(void* p, int rank, int world, void (*allreduce_dev)(double*, int), double* dev_buffer,
@@ -1504,7 +1569,7 @@ int icpxh_goicp_registration(void* p, double* optMat16, double* stats8, double* 
         stats8[0] = h->go->optError; stats8[1] = h->go->initError; stats8[2] = h->go->icpError;
         stats8[3] = (double)h->go->rot_pops; stats8[4] = (double)h->go->inner_evals; stats8[5] = h->go->final_lb;
         stats8[6] = (double)h->go->launches; stats8[7] = h->go->sseThresh;
-        stats8[8] = (double)h->go->spec_hits; stats8[9] = (double)h->go->spec_misses; stats8[10] = (double)h->go->collectives;
+        stats8[8] = (double)h->go->spec_hits; stats8[9] = (double)h->go->spec_misses; stats8[10] = (double)h->go->collectives; stats8[11] = (double)h->go->search_steps;
         if (resN3) std::memcpy(resN3, r.resN3.data.data(), r.resN3.data.size() * sizeof(double));
     });
 }

@@ -325,6 +325,12 @@ public:
     // search never looks at another search's state.
     bool pipeline = true;
     bool tail_lookahead = true;   // the last few running searches of a step look further ahead (fewer, fuller batches; same decisions)
+    // The inner searches of a step run on the device from start to end (icpx_bnb_search_run): queues, decisions and the
+    // lists of cubes to bound stay there, the host enqueues steps and collects (best error, best cube) per search.
+    // Used when frontier_width is 1, the sums are the device's (not parity_sums) and no bound batch is shared between
+    // ranks; lookahead, tail_lookahead and pipeline then have nothing to do. Decisions are those of the host loop.
+    bool device_search = true;
+    long long search_steps = 0;   // steps the device searches of the last OuterBnB took (two launches each)
     long long max_rot_pops = 0;   // 0 = unlimited
     // world > 1, batched mode. true (default): the rotation cubes of a step (the popped one and the `speculate` searched
     // ahead with it) are dealt out to the ranks; each rank runs the complete inner searches of its cubes on its own GPU
@@ -349,6 +355,8 @@ private:
     int cur_level_of(const float* maxDistL) const;
     void eval_items(std::vector<icpx_bnb_item>& items, std::vector<float>& ub, std::vector<float>& lb);
     void run_searches(const std::vector<Search*>& ss);
+    void run_searches_host(const std::vector<Search*>& ss);
+    bool run_searches_device(const std::vector<Search*>& ss, std::vector<Search*>& left);
     void submit_parents(int slot, const std::vector<icpx_bnb_item>& parents);
     void collect_parents(int slot, std::vector<float>& ub, std::vector<float>& lb);
     bool shared_launches() const { return comm.world > 1 && !(shard_cubes && batched); }   // every launch cut into shares

@@ -86,6 +86,8 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
         if (v && sscanf(v, "%lld,%lld", &a, &b2) == 2 && a >= 0 && b2 >= 0) { ctx->icp_walk_all_tiles = (size_t)a; ctx->icp_ball_min_tiles = (size_t)b2; }
     }
     { const char* v = getenv("ICPX_CAND"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) { ctx->cand_enable = a != 0; if (a > 1) ctx->cand_max_entries = (size_t)a; } }
+    { const char* v = getenv("ICPX_SEARCH_STEPS"); int x = 0; if (v && sscanf(v, "%d", &x) == 1 && x >= 1) ctx->search_max_steps = x; }
+    { const char* v = getenv("ICPX_SEARCH_LOT"); int x = 0, y = 0; if (v && sscanf(v, "%d,%d", &x, &y) == 2 && x >= 1 && y >= x) { ctx->search_lot = x; ctx->search_lot_max = y; } }
     { const char* v = getenv("ICPX_BALL_FEW"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->icp_ball_few = (unsigned)a; }
     { const char* v = getenv("ICPX_BALL_MANY"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->icp_ball_many = (unsigned)a; }
     // ICPX_BNB_GROUP_MIN: bound batches of at least this many items go through the kernel that takes eight items per
@@ -95,7 +97,7 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
         long long a = 0;
         if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->bnb_group_min = (size_t)a;
         v = getenv("ICPX_BNB_BRICKS");
-        if (v && v[0] == '0') ctx->bnb_bricks = false;
+        if (v && v[0] >= '0' && v[0] <= '2' && !v[1]) ctx->bnb_bricks = v[0] - '0';
     }
     if (icpx_bnb_scratch_init(ctx) != ICPX_OK) {
         g_create_error = "icpx_create: " + ctx->err;
@@ -115,10 +117,12 @@ extern "C" void icpx_destroy(icpx_ctx* ctx) {
                       &ctx->sort_vals_a, &ctx->sort_vals_b, &ctx->sort_tmp, &ctx->cand_tab, &ctx->cand_tmp, &ctx->src_pts, &ctx->nn_seed, &ctx->nn_pair, &ctx->walk_queue, &ctx->tile_counters, &ctx->partials, &ctx->sums,
                       &ctx->scratch_q, &ctx->scratch_idx, &ctx->scratch_d2, &ctx->scratch_f, &ctx->edt_bits,
                       &ctx->edt_rowlist, &ctx->edt_rowcnt, &ctx->edt_planelist, &ctx->edt_counters, &ctx->trim_keys_a, &ctx->trim_keys_b, &ctx->trim_vals_a, &ctx->trim_vals_b, &ctx->trim_p, &ctx->trim_idx, &ctx->edt_spill, &ctx->edt_plane,
-                      &ctx->edt_sq, &ctx->edt_bricks, &ctx->data_pts, &ctx->maxrot, &ctx->bnb_items, &ctx->bnb_partials,
+                      &ctx->edt_sq, &ctx->edt_bricks, &ctx->edt_fbricks, &ctx->data_pts, &ctx->maxrot, &ctx->bnb_items, &ctx->bnb_partials,
                       &ctx->bnb_mindis};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (DevBuf& b : ctx->search_buf)
+        if (b.p) (void)hipFree(b.p);
     if (ctx->bnb_pin) (void)hipHostFree(ctx->bnb_pin);
     for (BnbSlot& sl : ctx->bnb_slot) {
         for (DevBuf* b : {&sl.parents, &sl.items, &sl.partials})

@@ -28,6 +28,7 @@ struct EdtView {
     float mnx, mny, mnz, cell;
     const unsigned short* __restrict__ bricks;   // the same values in bricks of 4 x 4 x 4 voxels (see k_edt_bricks), or NULL
     int nb;                                      // bricks per axis
+    const float* __restrict__ fbricks;           // the distances themselves (float) in the same brick order (see k_edt_fbricks), or NULL
 };
 
 // norm in float (the SQ() macro multiplies floats and std::sqrt picks the float overload,
@@ -117,6 +118,22 @@ __global__ void k_edt_bricks(const int* __restrict__ sq, int div, int nb, unsign
     out[e] = (unsigned short)v;
 }
 
+// The bricks once more with the distance itself in place of the squared cell count: sqrt(v) * cell, rounded as
+// LDT::Distance rounds it (edt_distance_at), so that the bound kernel reads what it would otherwise compute for every
+// lookup (a conversion, a square root made exact, a product: a third of its instructions). 256 bytes per brick.
+__global__ void k_edt_fbricks(const int* __restrict__ sq, int div, int nb, float cell, float* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)nb * nb * nb * 64;
+    if (e >= total) return;
+    const unsigned b = (unsigned)(e >> 6), in = (unsigned)(e & 63);
+    const unsigned bz = b % nb, by = b / nb % nb, bx = b / nb / nb;
+    const unsigned x = bx * 4 + (in >> 4), y = by * 4 + (in >> 2 & 3), z = bz * 4 + (in & 3);
+    float v = 0.f;
+    if (x < (unsigned)div && y < (unsigned)div && z < (unsigned)div)
+        v = __fmul_rn(edt_sqrt_of_int((float)sq[((size_t)x * div + y) * div + z]), cell);
+    out[e] = v;
+}
+
 // One step of the butterfly over 2 * CNT values per lane: the lanes with bit `o` set keep the upper CNT values and
 // hand the lower ones to their partner l ^ o, the others the other way round; each adds what it receives.
 template <int CNT>
@@ -141,17 +158,15 @@ static __device__ __forceinline__ bool same_bits(float a, float b) { return __fl
 // operations on the same operands as there and added in the same order, so the bounds are the same bits.
 // PARENTS: `items` holds one record per family, the parent cube, and the eight children are formed here as the search
 // forms them (src/GoIcp.cpp:378-390: w' = w / 2, corner + (0 or 1) w' per axis, in float).
-template <bool BRICKS, bool PARENTS>
-__global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
-                                                   const icpx_bnb_item* __restrict__ items, int nitems, int nsplit, double* __restrict__ partials,
-                                                   float* __restrict__ mindis) {
-    __shared__ double sm[2][4];
-    __shared__ double sm8[16][4];
-    const int first = blockIdx.x * 8, split = blockIdx.y;
+template <int BRICKS, bool PARENTS>      // BRICKS: 0 the [x][y][z] grid, 1 the 16-bit bricks, 2 the float bricks
+static __device__ __forceinline__ void bnb_eval8_body(const EdtView& e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
+                                                      const icpx_bnb_item* __restrict__ items, int nitems, int nsplit, double* __restrict__ partials,
+                                                      float* __restrict__ mindis, const int block, const int split, double (*sm)[4], double (*sm8)[4]) {
+    const int first = block * 8;
     icpx_bnb_item it;
     float tx[2], ty[2], tz[2];
     if (PARENTS) {
-        it = items[blockIdx.x];
+        it = items[block];
         it.w = it.w * 0.5f;                     // (float)(parent.w / 2.0): exact either way
         const float half = it.w / 2;
         tx[0] = it.x + half; tx[1] = (it.x + it.w) + half;
@@ -192,6 +207,7 @@ __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __re
     const float inv = __frcp_rn(e.cell);
     const __amdgpu_buffer_rsrc_t grid = edt_grid_rsrc(e.sq);
     const __amdgpu_buffer_rsrc_t bricks = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(e.bricks), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fbricks = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.fbricks), 0, -1, 0x00020000);
     const size_t per = (n + nsplit - 1) / nsplit;
     const size_t lo = (size_t)split * per, hi = lo + per < n ? lo + per : n;
     double ub[8], lb[8];
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __re
         const unsigned cx[2] = {edt_axis_cell(ax[0], e.div), edt_axis_cell(ax[1], e.div)}, cy[2] = {edt_axis_cell(ay[0], e.div), edt_axis_cell(ay[1], e.div)},
                        cz[2] = {edt_axis_cell(az[0], e.div), edt_axis_cell(az[1], e.div)};
         const bool outside = fmaxf(fmaxf(fmaxf(ax[0].over, ax[1].over), fmaxf(ay[0].over, ay[1].over)), fmaxf(az[0].over, az[1].over)) != 0.f;
-        float g[8];
+        float g[8], d[8];
         if (BRICKS) {
             // a voxel's place in the brick copy is a sum of one term per axis
             unsigned xo[2], xyo[4], zo[2];
@@ -235,6 +251,10 @@ __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __re
             }
 #pragma unroll
             for (int s = 0; s < 4; s++) xyo[s] = xo[s & 1] + (cy[s >> 1] >> 2) * (unsigned)(e.nb * 64) + (cy[s >> 1] & 3) * 4;
+            if (BRICKS == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) d[j] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(fbricks, (int)((xyo[j & 3] + zo[j >> 2]) * 4u), 0, 0));
+            } else {
             unsigned v[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(bricks, (int)((xyo[j & 3] + zo[j >> 2]) * 2u), 0, 0) & 0xffffu;
@@ -247,6 +267,7 @@ __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __re
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) g[j] = (float)v[j];
+            }
         } else {
             unsigned xoff[2], xyoff[4];
 #pragma unroll
@@ -257,9 +278,10 @@ __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __re
             for (int j = 0; j < 8; j++)
                 g[j] = (float)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)((xyoff[j & 3] + cz[j >> 2]) * 4u), 0, 0);
         }
-        float d[8];
+        if (BRICKS != 2) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) d[j] = __fmul_rn(edt_sqrt_of_int(g[j]), e.cell);
+            for (int j = 0; j < 8; j++) d[j] = __fmul_rn(edt_sqrt_of_int(g[j]), e.cell);
+        }
         if (__any(outside)) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -304,6 +326,31 @@ __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __re
     if (threadIdx.x < 16) {
         const double v = (sm8[threadIdx.x][0] + sm8[threadIdx.x][1]) + (sm8[threadIdx.x][2] + sm8[threadIdx.x][3]);
         partials[((size_t)(first + (threadIdx.x >> 1)) * nsplit + split) * 2 + (threadIdx.x & 1)] = v;
+    }
+}
+
+template <int BRICKS, bool PARENTS>
+__global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
+                                                   const icpx_bnb_item* __restrict__ items, int nitems, int nsplit, double* __restrict__ partials,
+                                                   float* __restrict__ mindis) {
+    __shared__ double sm[2][4];
+    __shared__ double sm8[16][4];
+    bnb_eval8_body<BRICKS, PARENTS>(e, data, n, maxrot, items, nitems, nsplit, partials, mindis, (int)blockIdx.x, (int)blockIdx.y, sm, sm8);
+}
+
+// The same over a list of parent cubes whose length is only known on the device (*count, written by the kernel that
+// made the list): workgroup (x, y) takes parents x, x + gridDim.x, ... of slice y, so a grid sized for an earlier,
+// longer list does no harm.
+template <int BRICKS>
+__global__ __launch_bounds__(256) void k_bnb_eval8_list(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
+                                                        const icpx_bnb_item* __restrict__ parents, const int* __restrict__ count, int nsplit,
+                                                        double* __restrict__ partials) {
+    __shared__ double sm[2][4];
+    __shared__ double sm8[16][4];
+    const int cnt = *count;
+    for (int a = (int)blockIdx.x; a < cnt; a += (int)gridDim.x) {
+        bnb_eval8_body<BRICKS, true>(e, data, n, maxrot, parents, 8 * cnt, nsplit, partials, nullptr, a, (int)blockIdx.y, sm, sm8);
+        __syncthreads();                     // the sums of this parent have been read before the next one's are written
     }
 }
 
@@ -358,6 +405,7 @@ EdtView edt_view(const icpx_ctx* ctx) {
     e.sq = ctx->edt_sq.as<int>(); e.div = (int)ctx->div;
     e.mnx = ctx->edt_min[0]; e.mny = ctx->edt_min[1]; e.mnz = ctx->edt_min[2]; e.cell = ctx->edt_cell;
     e.bricks = ctx->edt_bricks_ready ? ctx->edt_bricks.as<unsigned short>() : nullptr;
+    e.fbricks = ctx->edt_bricks_ready && ctx->edt_fbricks_ready ? ctx->edt_fbricks.as<float>() : nullptr;
     e.nb = ((int)ctx->div + 3) / 4;
     return e;
 }
@@ -462,6 +510,15 @@ static int bnb_bricks_ensure(icpx_ctx* ctx) {
     hipLaunchKernelGGL(k_edt_bricks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)ctx->edt_sq.as<int>(), (int)ctx->div, (int)nb,
                        ctx->edt_bricks.as<unsigned short>());
     ICPX_TRY(icpx_launch_check(ctx, "k_edt_bricks"));
+    // the float bricks take 256 bytes per 64 voxels: up to a gigabyte of them (grids of some 640 cells a side)
+    ctx->edt_fbricks_ready = false;
+    if (ctx->bnb_bricks == 2 && total * sizeof(float) <= ((size_t)1 << 30)) {
+        ICPX_TRY(icpx_reserve(ctx, ctx->edt_fbricks, total * sizeof(float)));
+        hipLaunchKernelGGL(k_edt_fbricks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)ctx->edt_sq.as<int>(), (int)ctx->div, (int)nb,
+                           ctx->edt_cell, ctx->edt_fbricks.as<float>());
+        ICPX_TRY(icpx_launch_check(ctx, "k_edt_fbricks"));
+        ctx->edt_fbricks_ready = true;
+    }
     ctx->edt_bricks_ready = true;
     return ICPX_OK;
 }
@@ -470,8 +527,8 @@ static int bnb_bricks_ensure(icpx_ctx* ctx) {
 // that takes eight items per workgroup reads the brick copy of the grid when there is one.
 static void bnb_launch(icpx_ctx* ctx, const icpx_bnb_item* items_dev, size_t nitems, int nsplit, double* partials, float* mindis_dev) {
     const size_t n = ctx->nd;
-    auto eight = k_bnb_eval8<false, false>;
-    if (ctx->edt_bricks_ready) eight = k_bnb_eval8<true, false>;
+    auto eight = k_bnb_eval8<0, false>;
+    if (ctx->edt_bricks_ready) eight = ctx->edt_fbricks_ready ? k_bnb_eval8<2, false> : k_bnb_eval8<1, false>;
     if (nitems >= ctx->bnb_group_min && nitems >= 8)
         hipLaunchKernelGGL(eight, dim3((unsigned)((nitems + 7) / 8), (unsigned)nsplit), dim3(256), 0,
                            ctx->stream, edt_view(ctx), ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), items_dev, (int)nitems, nsplit, partials, mindis_dev);
@@ -587,8 +644,8 @@ extern "C" int icpx_bnb_submit(icpx_ctx* ctx, int slot, const icpx_bnb_item* par
         std::memcpy(sl.pin, parents + first, count * sizeof(icpx_bnb_item));
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sl.parents.p, sl.pin, count * sizeof(icpx_bnb_item), hipMemcpyHostToDevice, st));
         if (eight) {
-            auto kernel = k_bnb_eval8<false, true>;
-            if (ctx->edt_bricks_ready) kernel = k_bnb_eval8<true, true>;
+            auto kernel = k_bnb_eval8<0, true>;
+            if (ctx->edt_bricks_ready) kernel = ctx->edt_fbricks_ready ? k_bnb_eval8<2, true> : k_bnb_eval8<1, true>;
             hipLaunchKernelGGL(kernel, dim3((unsigned)count, (unsigned)nsplit), dim3(256), 0, st,
                                edt_view(ctx), ctx->data_pts.as<float4>(), n, ctx->maxrot.as<float>(), sl.parents.as<icpx_bnb_item>(), (int)nchild, nsplit,
                                sl.partials.as<double>(), (float*)nullptr);
@@ -682,6 +739,228 @@ extern "C" int icpx_bnb_eval_noalloc(icpx_ctx* ctx, const icpx_bnb_item* items_d
     bnb_launch(ctx, items_dev, nitems, nsplit, part, nullptr);
     hipLaunchKernelGGL(k_bnb_reduce, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, ctx->stream, part, (int)nitems, 0, (int)nitems, nsplit, out_dev);
     return icpx_launch_check(ctx, "k_bnb_eval (noalloc)");
+}
+
+// ---- inner (translation) searches run on the device ---------------------------------------------------------------
+// GoIcp::innerBnB (src/GoIcp.cpp:353-457) keeps a priority queue of translation cubes: take the cube with the lowest
+// lower bound, bound its eight children, record a better upper bound, queue the children that can still hold a better
+// pose, stop when a child's lower bound comes within the threshold of the best error or the queue runs dry. A rotation
+// cube needs two such searches per child cube and they are independent of each other, so many run side by side; a step
+// of all of them is one launch of the bound kernel over the list of cubes taken (one per running search) and one launch
+// of k_search_step, which sums each cube's slices, takes the eight bounds as the loop above does, keeps the search's
+// queue and writes the next list. The host only enqueues steps and looks at the length of the list now and then.
+//
+// The queue is the binary heap of std::priority_queue<TransNode> (operator<: lb greater, src/GoIcp.cpp:35-42), moved by the push_heap /
+// pop_heap steps of the GNU C++ library, because cubes of equal lower bound (the many with lb = 0 near the root) leave
+// the queue in the order those steps give them, and that order decides which cube is expanded next.
+#define ICPX_SEARCH_HEAP_CAP 1024      // cubes a search can hold in its queue
+#define ICPX_SEARCH_MAX_STEPS 4096     // steps of one icpx_bnb_search_run call
+
+struct SearchState {
+    float R[9];
+    int level;
+    float opt;                // best error so far (optErrorT)
+    int have_best;
+    float best[4];            // the cube that gave it
+    float parent[4];          // the cube whose children are being bounded
+    int count;                // cubes in the queue
+    int done, pops, status;
+};
+
+__global__ void k_search_start(const icpx_bnb_search* __restrict__ in, int n, SearchState* __restrict__ st, int* __restrict__ active,
+                               icpx_bnb_item* __restrict__ parents, int* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) cnt[0] = n;
+    if (i >= n) return;
+    const icpx_bnb_search q = in[i];
+    SearchState s;
+    icpx_bnb_item it;
+    for (int k = 0; k < 9; k++) { s.R[k] = q.R[k]; it.R[k] = q.R[k]; }
+    s.level = q.level; it.level = q.level;
+    s.opt = q.opt_error;
+    s.have_best = 0;
+    for (int k = 0; k < 4; k++) { s.best[k] = 0.f; s.parent[k] = q.cube[k]; }
+    it.x = q.cube[0]; it.y = q.cube[1]; it.z = q.cube[2]; it.w = q.cube[3];
+    s.count = 0; s.done = 0; s.pops = 0; s.status = 0;
+    st[i] = s;
+    active[i] = i;
+    parents[i] = it;
+}
+
+// One step of the running searches: workgroup (one wave) a takes the bounds of the eight children of active search a.
+__global__ __launch_bounds__(64) void k_search_step(SearchState* __restrict__ states, float4* __restrict__ heap_cube, float* __restrict__ heap_lb,
+                                                    const double* __restrict__ partials, int nsplit, const int* __restrict__ active_in,
+                                                    const int* __restrict__ cnt_in, int* __restrict__ active_out, int* __restrict__ cnt_out,
+                                                    icpx_bnb_item* __restrict__ parents_out, float sse_thresh) {
+    __shared__ float4 h_cube[ICPX_SEARCH_HEAP_CAP];
+    __shared__ float h_lb[ICPX_SEARCH_HEAP_CAP];
+    __shared__ float s_bound[16];
+    __shared__ int s_n;
+    const int lane = (int)threadIdx.x;
+    const int cnt = *cnt_in;
+    for (int a = (int)blockIdx.x; a < cnt; a += (int)gridDim.x) {
+        const int sid = active_in[a];
+        if (lane < 16) {
+            // child lane >> 1, ub (even lanes) or lb (odd): the slices in order from zero, as k_bnb_reduce adds them
+            double v = 0.0;
+            for (int sl = 0; sl < nsplit; sl++) v += partials[((size_t)(a * 8 + (lane >> 1)) * nsplit + sl) * 2 + (lane & 1)];
+            s_bound[lane] = (float)v;
+        }
+        const int n0 = states[sid].count;
+        const size_t hbase = (size_t)sid * ICPX_SEARCH_HEAP_CAP;
+        for (int k = lane; k < n0; k += 64) { h_cube[k] = heap_cube[hbase + k]; h_lb[k] = heap_lb[hbase + k]; }
+        __syncthreads();
+        if (lane == 0) {
+            SearchState s = states[sid];
+            int n = n0;
+            s.pops++;
+            const float w2 = s.parent[3] * 0.5f;              // (float)(w / 2.0), exact
+            for (int j = 0; j < 8 && !s.done; j++) {
+                const float cx = s.parent[0] + (float)(j & 1) * w2, cy = s.parent[1] + (float)(j >> 1 & 1) * w2, cz = s.parent[2] + (float)(j >> 2 & 1) * w2;
+                const float u = s_bound[2 * j], l = s_bound[2 * j + 1];
+                if (u < s.opt) { s.opt = u; s.best[0] = cx; s.best[1] = cy; s.best[2] = cz; s.best[3] = w2; s.have_best = 1; }
+                if (l >= s.opt) continue;
+                if ((double)s.opt - (double)l < (double)sse_thresh) { s.done = 1; continue; }
+                if (n >= ICPX_SEARCH_HEAP_CAP) { s.done = 1; s.status = 1; continue; }
+                // push_heap: the new cube moves up past every parent with a greater lower bound
+                int hole = n++;
+                while (hole > 0) {
+                    const int par = (hole - 1) / 2;
+                    if (!(h_lb[par] > l)) break;
+                    h_cube[hole] = h_cube[par]; h_lb[hole] = h_lb[par];
+                    hole = par;
+                }
+                h_cube[hole] = make_float4(cx, cy, cz, w2); h_lb[hole] = l;
+            }
+            if (!s.done && n == 0) s.done = 1;
+            if (!s.done) {
+                // pop_heap: the top leaves, the hole moves down along the children with the smaller lower bound (the left
+                // one when equal), and the last cube is pushed up from there
+                const float4 top = h_cube[0];
+                n--;
+                if (n > 0) {
+                    const float4 vc = h_cube[n];
+                    const float vl = h_lb[n];
+                    const int len = n;
+                    int hole = 0, child = 0;
+                    while (child < (len - 1) / 2) {
+                        child = 2 * (child + 1);
+                        if (h_lb[child] > h_lb[child - 1]) child--;
+                        h_cube[hole] = h_cube[child]; h_lb[hole] = h_lb[child];
+                        hole = child;
+                    }
+                    if ((len & 1) == 0 && child == (len - 2) / 2) {
+                        child = 2 * (child + 1);
+                        h_cube[hole] = h_cube[child - 1]; h_lb[hole] = h_lb[child - 1];
+                        hole = child - 1;
+                    }
+                    while (hole > 0) {
+                        const int par = (hole - 1) / 2;
+                        if (!(h_lb[par] > vl)) break;
+                        h_cube[hole] = h_cube[par]; h_lb[hole] = h_lb[par];
+                        hole = par;
+                    }
+                    h_cube[hole] = vc; h_lb[hole] = vl;
+                }
+                s.parent[0] = top.x; s.parent[1] = top.y; s.parent[2] = top.z; s.parent[3] = top.w;
+                const int slot = atomicAdd(cnt_out, 1);
+                active_out[slot] = sid;
+                icpx_bnb_item it;
+                for (int k = 0; k < 9; k++) it.R[k] = s.R[k];
+                it.x = top.x; it.y = top.y; it.z = top.z; it.w = top.w; it.level = s.level;
+                parents_out[slot] = it;
+            }
+            s.count = n;
+            states[sid] = s;
+            s_n = s.done ? 0 : n;           // a finished search's queue is not read again
+        }
+        __syncthreads();
+        const int n1 = s_n;
+        for (int k = lane; k < n1; k += 64) { heap_cube[hbase + k] = h_cube[k]; heap_lb[hbase + k] = h_lb[k]; }
+        __syncthreads();
+    }
+}
+
+__global__ void k_search_finish(const SearchState* __restrict__ st, int n, const int* __restrict__ left, icpx_bnb_found* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SearchState s = st[i];
+    icpx_bnb_found f;
+    f.opt_error = s.opt;
+    f.have_best = s.have_best;
+    for (int k = 0; k < 4; k++) f.best[k] = s.best[k];
+    f.cubes = s.pops;
+    f.status = s.status ? s.status : (s.done ? 0 : 2);      // 2: still running when the steps ran out
+    (void)left;
+    out[i] = f;
+}
+
+extern "C" int icpx_bnb_search_run(icpx_ctx* ctx, const icpx_bnb_search* searches, size_t n, float sse_thresh, icpx_bnb_found* found, long long* steps_out) {
+    if (!ctx) return ICPX_EINVAL;
+    if (steps_out) *steps_out = 0;
+    if (n == 0) return ICPX_OK;
+    if (!searches || !found) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_search_run: NULL argument");
+    if (n > (size_t)1 << 20) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_bnb_search_run: more than 1048576 searches in one call");
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_search_run: no EDT has been built");
+    if (ctx->nd == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_search_run: no data cloud (call icpx_goicp_set_data first)");
+    for (size_t i = 0; i < n; i++)
+        if (searches[i].level >= ICPX_MAXROTLEVEL) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_search_run: search %zu has level %d >= %d", i, searches[i].level, ICPX_MAXROTLEVEL);
+    ICPX_TRY(icpx_bind(ctx));
+    if (ctx->bnb_bricks) ICPX_TRY(bnb_bricks_ensure(ctx));
+    const size_t nd = ctx->nd;
+    const int nsplit = bnb_slices(nd);
+    DevBuf* sb = ctx->search_buf;
+    ICPX_TRY(icpx_reserve(ctx, sb[0], n * sizeof(SearchState)));
+    ICPX_TRY(icpx_reserve(ctx, sb[1], n * ICPX_SEARCH_HEAP_CAP * sizeof(float4)));
+    ICPX_TRY(icpx_reserve(ctx, sb[2], n * ICPX_SEARCH_HEAP_CAP * sizeof(float)));
+    ICPX_TRY(icpx_reserve(ctx, sb[3], 2 * n * sizeof(int)));
+    ICPX_TRY(icpx_reserve(ctx, sb[4], 2 * n * sizeof(icpx_bnb_item)));
+    ICPX_TRY(icpx_reserve(ctx, sb[5], n * 8 * (size_t)nsplit * 2 * sizeof(double)));
+    ICPX_TRY(icpx_reserve(ctx, sb[6], (ICPX_SEARCH_MAX_STEPS + 1) * sizeof(int)));
+    ICPX_TRY(icpx_reserve(ctx, sb[7], n * std::max(sizeof(icpx_bnb_search), sizeof(icpx_bnb_found))));
+    SearchState* st = sb[0].as<SearchState>();
+    int* active = sb[3].as<int>();
+    icpx_bnb_item* parents = sb[4].as<icpx_bnb_item>();
+    int* cnt = sb[6].as<int>();
+    const size_t io_bytes = n * std::max(sizeof(icpx_bnb_search), sizeof(icpx_bnb_found));
+    ICPX_TRY(bnb_pin_reserve(ctx, io_bytes + 64));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));       // an earlier transfer may still use the staging area
+    int* pin_cnt = reinterpret_cast<int*>(static_cast<char*>(ctx->bnb_pin) + io_bytes);
+    std::memcpy(ctx->bnb_pin, searches, n * sizeof(icpx_bnb_search));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sb[7].p, ctx->bnb_pin, n * sizeof(icpx_bnb_search), hipMemcpyHostToDevice, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipMemsetAsync(cnt, 0, (ICPX_SEARCH_MAX_STEPS + 1) * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_search_start, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sb[7].as<icpx_bnb_search>(), (int)n, st, active, parents, cnt);
+    auto eval = !ctx->edt_bricks_ready ? k_bnb_eval8_list<0> : ctx->edt_fbricks_ready ? k_bnb_eval8_list<2> : k_bnb_eval8_list<1>;
+    const EdtView view = edt_view(ctx);
+    size_t running = n;            // an upper bound on the searches still running
+    int step = 0;
+    // Steps are enqueued a few at a time; after each lot the length of the list comes back. Few steps per lot at first
+    // (most searches end within a handful and the grids shrink with the list), more once only the long searches are left.
+    int lot = ctx->search_lot;
+    const int max_steps = std::min(ctx->search_max_steps, ICPX_SEARCH_MAX_STEPS);
+    while (running > 0 && step < max_steps) {
+        const int upto = std::min(step + lot, max_steps);
+        const unsigned gx = (unsigned)std::min<size_t>(running, (size_t)ctx->num_cus * 4), gs = (unsigned)std::min<size_t>(running, (size_t)ctx->num_cus * 8);
+        for (; step < upto; step++) {
+            const int in = step & 1, out = in ^ 1;
+            hipLaunchKernelGGL(eval, dim3(gx, (unsigned)nsplit), dim3(256), 0, ctx->stream, view, ctx->data_pts.as<float4>(), nd, ctx->maxrot.as<float>(),
+                               parents + (size_t)in * n, cnt + step, nsplit, sb[5].as<double>());
+            hipLaunchKernelGGL(k_search_step, dim3(gs), dim3(64), 0, ctx->stream, st, sb[1].as<float4>(), sb[2].as<float>(), sb[5].as<double>(), nsplit,
+                               active + (size_t)in * n, cnt + step, active + (size_t)out * n, cnt + step + 1, parents + (size_t)out * n, sse_thresh);
+        }
+        ICPX_TRY(icpx_launch_check(ctx, "k_search_step"));
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(pin_cnt, cnt + step, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        running = (size_t)*pin_cnt;
+        lot = std::min(2 * lot, ctx->search_lot_max);
+    }
+    hipLaunchKernelGGL(k_search_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, st, (int)n, cnt + step, sb[7].as<icpx_bnb_found>());
+    ICPX_TRY(icpx_launch_check(ctx, "k_search_finish"));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->bnb_pin, sb[7].p, n * sizeof(icpx_bnb_found), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(found, ctx->bnb_pin, n * sizeof(icpx_bnb_found));
+    if (steps_out) *steps_out = step;
+    return ICPX_OK;
 }
 
 extern "C" int icpx_goicp_residuals(icpx_ctx* ctx, const double T[16], float* dist_out) {

@@ -112,7 +112,8 @@ struct icpx_ctx {
     DevBuf edt_plane;        // div^3 int32: in-plane squared distances (only non-empty planes written)
     DevBuf edt_sq;           // div^3 int32: squared EDT, [x][y][z]
     DevBuf edt_bricks;       // the same values as uint16 in bricks of 4 x 4 x 4 voxels, for the bound kernel (made on first use after a build)
-    bool edt_bricks_ready = false;
+    DevBuf edt_fbricks;      // the distances (float) in the same brick order (bnb_bricks == 2)
+    bool edt_bricks_ready = false, edt_fbricks_ready = false;
 
     // ---- Go-ICP ---------------------------------------------------------------------------------------
     size_t nd = 0;
@@ -123,10 +124,13 @@ struct icpx_ctx {
     // cube for the families of eight sibling cubes the search sends, an eighth of the workgroups); smaller ones one item
     // per workgroup, which fills the chip from 128 items on. Same bounds either way. ICPX_BNB_GROUP_MIN overrides.
     size_t bnb_group_min = 256;
-    bool bnb_bricks = true;      // false (ICPX_BNB_BRICKS=0): the bound kernel reads the [x][y][z] grid only
+    int bnb_bricks = 2;          // ICPX_BNB_BRICKS: 0 the bound kernel reads the [x][y][z] grid only, 1 the 16-bit bricks, 2 the float bricks
     double* pin_sums = nullptr;  // pinned host memory for the ICPX_NSUMS sums of an ICP pass: the reduction kernel writes them there itself
     double* bnb_scratch = nullptr;   // this GPU's address of the fixed partial-sum area of icpx_bnb_eval_noalloc (resolved at icpx_create)
     BnbSlot bnb_slot[ICPX_BNB_SLOTS];
+    DevBuf search_buf[8];        // icpx_bnb_search_run: states, queues (cubes, bounds), lists, parent records, partial sums, list lengths, in / out records
+    int search_max_steps = 4096; // steps after which icpx_bnb_search_run gives up on the searches still running (ICPX_SEARCH_STEPS lowers it)
+    int search_lot = 4, search_lot_max = 16;   // steps enqueued between two looks at the list length: first lot, and the most (ICPX_SEARCH_LOT=first,most)
     void* bnb_pin = nullptr;     // pinned host staging of a bound batch: the items going up, then ub / lb coming down
     size_t bnb_pin_cap = 0;
 

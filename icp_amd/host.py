@@ -46,6 +46,7 @@ def _lib():
         lib.icpxh_goicp_exact_residuals.argtypes = [C.c_void_p, C.c_int]
         lib.icpxh_goicp_pipeline.argtypes = [C.c_void_p, C.c_int]
         lib.icpxh_goicp_tail_lookahead.argtypes = [C.c_void_p, C.c_int]
+        lib.icpxh_goicp_device_search.argtypes = [C.c_void_p, C.c_int]
         lib.icpxh_goicp_set_collective_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.icpxh_goicp_set_collective.argtypes = [C.c_void_p, C.c_int, C.c_int, _ALLREDUCE]
         lib.icpxh_goicp_registration.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -277,12 +278,13 @@ class GoIcp:
             _ck(_lib().icpxh_goicp_set_collective(self._h, rank, world, self._cb))
 
     def options(self, run_bnb=True, batched=True, parity_sums=False, frontier_width=1, max_rot_pops=0, lookahead=4, speculate=0,
-                exact_residuals=False, pipeline=True, tail_lookahead=True, shard_cubes=True):
+                exact_residuals=False, pipeline=True, tail_lookahead=True, shard_cubes=True, device_search=True):
         _ck(_lib().icpxh_goicp_options(self._h, int(run_bnb), int(batched), int(parity_sums), frontier_width, max_rot_pops, lookahead, speculate))
         _lib().icpxh_goicp_exact_residuals(self._h, int(exact_residuals))
         _lib().icpxh_goicp_pipeline(self._h, int(pipeline))
         _lib().icpxh_goicp_tail_lookahead(self._h, int(tail_lookahead))
         _lib().icpxh_goicp_shard_cubes(self._h, int(shard_cubes))
+        _lib().icpxh_goicp_device_search(self._h, int(device_search))
         return self
 
     def registration(self, want_points=False):
@@ -291,7 +293,7 @@ class GoIcp:
         _ck(_lib().icpxh_goicp_registration(self._h, _vp(M), _vp(st), _vp(res)))
         return dict(optMat=M.reshape(4, 4), optError=np.float32(st[0]), initError=np.float32(st[1]), icpError=np.float32(st[2]),
                     rot_pops=int(st[3]), inner_evals=int(st[4]), lb=st[5], launches=int(st[6]), sseThresh=st[7], spec_hits=int(st[8]),
-                    spec_misses=int(st[9]), collectives=int(st[10]), resN3=res)
+                    spec_misses=int(st[9]), collectives=int(st[10]), search_steps=int(st[11]), resN3=res)
 
     def innerBnB(self, R, level, optError):
         R = _f32(R).reshape(9); out = C.c_float(); tr = np.empty(4, np.float32)

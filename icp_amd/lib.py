@@ -26,6 +26,16 @@ class BnbItem(C.Structure):
                 ("level", C.c_int32)]
 
 
+class BnbSearch(C.Structure):
+    """icpx_bnb_search of include/icpx.h."""
+    _fields_ = [("R", C.c_float * 9), ("level", C.c_int32), ("opt_error", C.c_float), ("cube", C.c_float * 4)]
+
+
+class BnbFound(C.Structure):
+    """icpx_bnb_found of include/icpx.h."""
+    _fields_ = [("opt_error", C.c_float), ("have_best", C.c_int32), ("best", C.c_float * 4), ("cubes", C.c_int32), ("status", C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/icpx.h declares
 ICPX_SYMBOLS = {
     "icpx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -59,6 +69,7 @@ ICPX_SYMBOLS = {
     "icpx_goicp_read_maxrotdist": (C.c_int, [C.c_void_p, C.c_void_p]),
     "icpx_bnb_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "icpx_bnb_eval_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "icpx_bnb_search_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.POINTER(C.c_longlong)]),
     "icpx_bnb_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
     "icpx_bnb_collect": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "icpx_bnb_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -233,6 +233,33 @@ int icpx_bnb_collect(icpx_ctx* ctx, int slot, double* ub, double* lb);
  * icpx_bnb_collect waits for that copy and hands out ub / lb as for a batch submitted with out_dev == NULL. */
 int icpx_bnb_fetch(icpx_ctx* ctx, int slot, const double* out_dev);
 
+/* Whole inner searches on the device: the loop of GoIcp::innerBnB (src/GoIcp.cpp:353-457) for n independent
+ * (rotation, level) pairs at once, each from its own starting cube and best error so far. Per search: the priority queue
+ * of translation cubes (lowest lower bound first, equal bounds in the order std::priority_queue<TransNode> gives them,
+ * :361, :371), the eight children of the cube taken (:378-390), their bounds as icpx_bnb_eval gives them, the better
+ * upper bound recorded with its cube (:432-437), children with lb >= best error dropped (:439), the search ended by
+ * the first child whose lb is within sse_thresh of the best error (:446-450; float minus double, compared in double as
+ * there) or by an empty queue (:367). The steps of all searches run as launches on the context's stream without the host in between; the call
+ * returns when every search has ended.
+ * found[i]: the best error (the starting value if no child improved on it), whether a cube gave it and that cube, the
+ * cubes taken off the queue (8 bound evaluations each) and status: 0 ended as above; 1 the queue outgrew 1024 cubes;
+ * 2 still running after 4096 steps. A search with status != 0 holds no result: run it by other means
+ * (icpx_bnb_submit). steps_out (may be NULL): steps enqueued (two launches each). */
+typedef struct icpx_bnb_search {
+    float R[9];       /* rotation, row-major */
+    int32_t level;    /* as icpx_bnb_item.level */
+    float opt_error;  /* best error when the search starts (optErrorT = optError, :356) */
+    float cube[4];    /* the starting cube: corner x, y, z and side (initNodeTrans, :359) */
+} icpx_bnb_search;
+typedef struct icpx_bnb_found {
+    float opt_error;
+    int32_t have_best;
+    float best[4];
+    int32_t cubes;
+    int32_t status;
+} icpx_bnb_found;
+int icpx_bnb_search_run(icpx_ctx* ctx, const icpx_bnb_search* searches, size_t n, float sse_thresh, icpx_bnb_found* found, long long* steps_out);
+
 /* Waits for the context's stream and copies `bytes` of device memory to host memory (results of the _async entry
  * points that the caller left in its own device buffers). No counterpart in the reference. */
 int icpx_download(icpx_ctx* ctx, const void* dev, void* host, size_t bytes);

@@ -107,8 +107,9 @@ def test_goicp_two_ranks_share_every_batch_on_the_device(tmp_path, bunny000, bun
     from icp_amd.host import GoIcp
     m, d = _pair(bunny000, bun270, 8)
     # one rank: the searches advance as two groups whose batches alternate on the GPU (as with several ranks), or as one group
-    piped = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, lookahead=4, speculate=speculate).registration()
-    one = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, lookahead=4, speculate=speculate, pipeline=False).registration()
+    # (the searches driven by the host: what the ranks do when they share every batch)
+    piped = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, lookahead=4, speculate=speculate, device_search=False).registration()
+    one = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, lookahead=4, speculate=speculate, pipeline=False, device_search=False).registration()
     for k in ("optError", "lb", "rot_pops", "spec_hits"):     # (how far the last running searches look ahead depends on the group: not inner_evals)
         assert piped[k] == one[k], k
     assert np.array_equal(piped["optMat"], one["optMat"]) and piped["launches"] > one["launches"]

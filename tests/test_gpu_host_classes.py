@@ -270,13 +270,18 @@ def test_goicp_bunny270_against_oracle_golden(bunny000, bun270):
     # rotation cubes, bit-identical optimum and lower bound, in fewer launches
     # (tail_lookahead, the wider look-ahead of the last running searches of a step, would make the two settings alike
     # here, where a step has only 16 searches; it is compared separately)
-    r1 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=0, tail_lookahead=False).registration()
-    r4 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=4, tail_lookahead=False).registration()
-    rt = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=0).registration()
+    # (this is about the host-driven loop; with the searches on the device there is nothing to look ahead for)
+    r1 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=0, tail_lookahead=False, device_search=False).registration()
+    r4 = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=4, tail_lookahead=False, device_search=False).registration()
+    rt = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1, lookahead=0, device_search=False).registration()
     for r in (r4, rt):
         assert r["rot_pops"] == r1["rot_pops"] and float(r["optError"]) == float(r1["optError"]) and r["lb"] == r1["lb"]
         assert np.array_equal(r["optMat"], r1["optMat"])
         assert r["launches"] < r1["launches"]
+    # and the searches run on the device (the default above): the decisions and the very bound evaluations of r1
+    rd = GoIcp(m, d, mse=1e-3, dt_div=300).options(batched=True, frontier_width=1).registration()
+    assert rd["search_steps"] > 0 and rd["rot_pops"] == r1["rot_pops"] and rd["inner_evals"] == r1["inner_evals"]
+    assert float(rd["optError"]) == float(r1["optError"]) and rd["lb"] == r1["lb"] and np.array_equal(rd["optMat"], r1["optMat"])
 
 
 @pytest.mark.parametrize("scale,remain", [(1.0, 100), (100.0, 100), (100.0, 80)])
