@@ -86,6 +86,7 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
         if (v && sscanf(v, "%lld,%lld", &a, &b2) == 2 && a >= 0 && b2 >= 0) { ctx->icp_walk_all_tiles = (size_t)a; ctx->icp_ball_min_tiles = (size_t)b2; }
     }
     { const char* v = getenv("ICPX_CAND"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) { ctx->cand_enable = a != 0; if (a > 1) ctx->cand_max_entries = (size_t)a; } }
+    { const char* v = getenv("ICPX_SEARCH_FEW"); int x = 0; if (v && sscanf(v, "%d", &x) == 1 && x >= 0) ctx->search_few = x; }
     { const char* v = getenv("ICPX_SEARCH_STEPS"); int x = 0; if (v && sscanf(v, "%d", &x) == 1 && x >= 1) ctx->search_max_steps = x; }
     { const char* v = getenv("ICPX_SEARCH_LOT"); int x = 0, y = 0; if (v && sscanf(v, "%d,%d", &x, &y) == 2 && x >= 1 && y >= x) { ctx->search_lot = x; ctx->search_lot_max = y; } }
     { const char* v = getenv("ICPX_BALL_FEW"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->icp_ball_few = (unsigned)a; }

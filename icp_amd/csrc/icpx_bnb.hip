@@ -158,7 +158,7 @@ static __device__ __forceinline__ bool same_bits(float a, float b) { return __fl
 // operations on the same operands as there and added in the same order, so the bounds are the same bits.
 // PARENTS: `items` holds one record per family, the parent cube, and the eight children are formed here as the search
 // forms them (src/GoIcp.cpp:378-390: w' = w / 2, corner + (0 or 1) w' per axis, in float).
-template <int BRICKS, bool PARENTS>      // BRICKS: 0 the [x][y][z] grid, 1 the 16-bit bricks, 2 the float bricks
+template <int BRICKS, bool PARENTS, int AHEAD = 1>      // BRICKS: 0 the [x][y][z] grid, 1 the 16-bit bricks, 2 the float bricks
 static __device__ __forceinline__ void bnb_eval8_body(const EdtView& e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
                                                       const icpx_bnb_item* __restrict__ items, int nitems, int nsplit, double* __restrict__ partials,
                                                       float* __restrict__ mindis, const int block, const int split, double (*sm)[4], double (*sm8)[4]) {
@@ -205,6 +205,7 @@ static __device__ __forceinline__ void bnb_eval8_body(const EdtView& e, const fl
     const float fdiv = (float)e.div;
     const float mxx = __fadd_rn(e.mnx, __fmul_rn(e.cell, fdiv)), mxy = __fadd_rn(e.mny, __fmul_rn(e.cell, fdiv)), mxz = __fadd_rn(e.mnz, __fmul_rn(e.cell, fdiv));
     const float inv = __frcp_rn(e.cell);
+    const float eps_near = (float)(e.div + 1) * 1e-6f;
     const __amdgpu_buffer_rsrc_t grid = edt_grid_rsrc(e.sq);
     const __amdgpu_buffer_rsrc_t bricks = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(e.bricks), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t fbricks = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.fbricks), 0, -1, 0x00020000);
@@ -213,95 +214,150 @@ static __device__ __forceinline__ void bnb_eval8_body(const EdtView& e, const fl
     double ub[8], lb[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) ub[j] = lb[j] = 0.0;
-    size_t i = lo + threadIdx.x;
-    float4 p_next = i < hi ? data[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float mr_next = mr && i < hi ? mr[i] : 0.f;
-    for (; i < hi; i += blockDim.x) {
-        const float4 p = p_next;
-        const float mr_i = mr_next;
-        if (i + blockDim.x < hi) { p_next = data[i + blockDim.x]; if (mr) mr_next = mr[i + blockDim.x]; }
-        const float rx = it.R[0] * p.x + it.R[1] * p.y + it.R[2] * p.z;
-        const float ry = it.R[3] * p.x + it.R[4] * p.y + it.R[5] * p.z;
-        const float rz = it.R[6] * p.x + it.R[7] * p.y + it.R[8] * p.z;
-        EdtAxis ax[2], ay[2], az[2];
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            ax[s] = edt_axis_begin(rx + tx[s], e.mnx, mxx, inv);
-            ay[s] = edt_axis_begin(ry + ty[s], e.mny, mxy, inv);
-            az[s] = edt_axis_begin(rz + tz[s], e.mnz, mxz, inv);
-        }
-        // the division itself only in waves where some lane needs it (the empty asm keeps the compiler from turning the
-        // branch into six unconditional divisions)
-        if (__any(ax[0].near || ax[1].near || ay[0].near || ay[1].near || az[0].near || az[1].near)) {
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int s = 0; s < 2; s++) { edt_axis_exact(ax[s], e.cell); edt_axis_exact(ay[s], e.cell); edt_axis_exact(az[s], e.cell); }
-        }
-        const unsigned cx[2] = {edt_axis_cell(ax[0], e.div), edt_axis_cell(ax[1], e.div)}, cy[2] = {edt_axis_cell(ay[0], e.div), edt_axis_cell(ay[1], e.div)},
-                       cz[2] = {edt_axis_cell(az[0], e.div), edt_axis_cell(az[1], e.div)};
-        const bool outside = fmaxf(fmaxf(fmaxf(ax[0].over, ax[1].over), fmaxf(ay[0].over, ay[1].over)), fmaxf(az[0].over, az[1].over)) != 0.f;
-        float g[8], d[8];
-        if (BRICKS) {
-            // a voxel's place in the brick copy is a sum of one term per axis
-            unsigned xo[2], xyo[4], zo[2];
-#pragma unroll
+    // One point in two parts, so that the lookups of several points can be in flight before the first is added up.
+    // lookup: the point rotated, the six cell coordinates of the family, the eight distances read (inside the box);
+    // returns whether some coordinate of some child lies outside the box. finish: the overshoot added where there is
+    // one, the rotation uncertainty subtracted, the terms of the sixteen sums added.
+    auto lookup = [&](const float4& p, float (&d)[8], float (&vv)[6]) -> bool {
+            const float rx = it.R[0] * p.x + it.R[1] * p.y + it.R[2] * p.z;
+            const float ry = it.R[3] * p.x + it.R[4] * p.y + it.R[5] * p.z;
+            const float rz = it.R[6] * p.x + it.R[7] * p.y + it.R[8] * p.z;
+            EdtAxis ax[2], ay[2], az[2];
+            const float vx[2] = {rx + tx[0], rx + tx[1]}, vy[2] = {ry + ty[0], ry + ty[1]}, vz[2] = {rz + tz[0], rz + tz[1]};
+            vv[0] = vx[0]; vv[1] = vx[1]; vv[2] = vy[0]; vv[3] = vy[1]; vv[4] = vz[0]; vv[5] = vz[1];
+            bool mv[6];
+    #pragma unroll
             for (int s = 0; s < 2; s++) {
-                xo[s] = (cx[s] >> 2) * (unsigned)(e.nb * e.nb * 64) + (cx[s] & 3) * 16;
-                zo[s] = (cz[s] >> 2) * 64 + (cz[s] & 3);
+                ax[s] = edt_axis_begin_inside(vx[s], e.mnx, mxx, inv, eps_near, mv[3 * s]);
+                ay[s] = edt_axis_begin_inside(vy[s], e.mny, mxy, inv, eps_near, mv[3 * s + 1]);
+                az[s] = edt_axis_begin_inside(vz[s], e.mnz, mxz, inv, eps_near, mv[3 * s + 2]);
             }
-#pragma unroll
-            for (int s = 0; s < 4; s++) xyo[s] = xo[s & 1] + (cy[s >> 1] >> 2) * (unsigned)(e.nb * 64) + (cy[s >> 1] & 3) * 4;
-            if (BRICKS == 2) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) d[j] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(fbricks, (int)((xyo[j & 3] + zo[j >> 2]) * 4u), 0, 0));
+            // some coordinate of some child outside the box (then the distances get the overshoot added, below)
+            const bool moved = (mv[0] | mv[1] | mv[2]) | (mv[3] | mv[4] | mv[5]);
+            // the division itself only in waves where some lane needs it (the empty asm keeps the compiler from turning the
+            // branch into six unconditional divisions)
+            if (__any(ax[0].near || ax[1].near || ay[0].near || ay[1].near || az[0].near || az[1].near)) {
+                asm volatile("" ::: "memory");
+    #pragma unroll
+                for (int s = 0; s < 2; s++) { edt_axis_exact(ax[s], e.cell); edt_axis_exact(ay[s], e.cell); edt_axis_exact(az[s], e.cell); }
+            }
+            const unsigned cx[2] = {edt_axis_cell_inside(ax[0], e.div), edt_axis_cell_inside(ax[1], e.div)},
+                           cy[2] = {edt_axis_cell_inside(ay[0], e.div), edt_axis_cell_inside(ay[1], e.div)},
+                           cz[2] = {edt_axis_cell_inside(az[0], e.div), edt_axis_cell_inside(az[1], e.div)};
+            float g[8];
+            if (BRICKS) {
+                // a voxel's place in the brick copy is a sum of one term per axis
+                unsigned xo[2], xyo[4], zo[2];
+    #pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    xo[s] = (cx[s] >> 2) * (unsigned)(e.nb * e.nb * 64) + (cx[s] & 3) * 16;
+                    zo[s] = (cz[s] >> 2) * 64 + (cz[s] & 3);
+                }
+    #pragma unroll
+                for (int s = 0; s < 4; s++) xyo[s] = xo[s & 1] + (cy[s >> 1] >> 2) * (unsigned)(e.nb * 64) + (cy[s >> 1] & 3) * 4;
+                if (BRICKS == 2) {
+    #pragma unroll
+                    for (int j = 0; j < 8; j++) d[j] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(fbricks, (int)((xyo[j & 3] + zo[j >> 2]) * 4u), 0, 0));
+                } else {
+                unsigned v[8];
+    #pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(bricks, (int)((xyo[j & 3] + zo[j >> 2]) * 2u), 0, 0) & 0xffffu;
+                const unsigned top = max(max(max(v[0], v[1]), max(v[2], v[3])), max(max(v[4], v[5]), max(v[6], v[7])));
+                if (__any(top == EDT_BRICK_ESCAPE)) {
+    #pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (v[j] == EDT_BRICK_ESCAPE)
+                            v[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(((cx[j & 1] * (unsigned)e.div + cy[j >> 1 & 1]) * (unsigned)e.div + cz[j >> 2]) * 4u), 0, 0);
+                }
+    #pragma unroll
+                for (int j = 0; j < 8; j++) g[j] = (float)v[j];
+                }
             } else {
-            unsigned v[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(bricks, (int)((xyo[j & 3] + zo[j >> 2]) * 2u), 0, 0) & 0xffffu;
-            const unsigned top = max(max(max(v[0], v[1]), max(v[2], v[3])), max(max(v[4], v[5]), max(v[6], v[7])));
-            if (__any(top == EDT_BRICK_ESCAPE)) {
-#pragma unroll
+                unsigned xoff[2], xyoff[4];
+    #pragma unroll
+                for (int s = 0; s < 2; s++) xoff[s] = cx[s] * (unsigned)e.div;
+    #pragma unroll
+                for (int s = 0; s < 4; s++) xyoff[s] = (xoff[s & 1] + cy[s >> 1]) * (unsigned)e.div;
+    #pragma unroll
                 for (int j = 0; j < 8; j++)
-                    if (v[j] == EDT_BRICK_ESCAPE)
-                        v[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(((cx[j & 1] * (unsigned)e.div + cy[j >> 1 & 1]) * (unsigned)e.div + cz[j >> 2]) * 4u), 0, 0);
+                    g[j] = (float)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)((xyoff[j & 3] + cz[j >> 2]) * 4u), 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < 8; j++) g[j] = (float)v[j];
+            if (BRICKS != 2) {
+    #pragma unroll
+                for (int j = 0; j < 8; j++) d[j] = __fmul_rn(edt_sqrt_of_int(g[j]), e.cell);
             }
-        } else {
-            unsigned xoff[2], xyoff[4];
-#pragma unroll
-            for (int s = 0; s < 2; s++) xoff[s] = cx[s] * (unsigned)e.div;
-#pragma unroll
-            for (int s = 0; s < 4; s++) xyoff[s] = (xoff[s & 1] + cy[s >> 1]) * (unsigned)e.div;
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                g[j] = (float)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)((xyoff[j & 3] + cz[j >> 2]) * 4u), 0, 0);
-        }
-        if (BRICKS != 2) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) d[j] = __fmul_rn(edt_sqrt_of_int(g[j]), e.cell);
-        }
-        if (__any(outside)) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float ox = ax[j & 1].over, oy = ay[j >> 1 & 1].over, oz = az[j >> 2].over;
-                if (ox != 0.f || oy != 0.f || oz != 0.f) {
-                    const double dx = (double)ox, dy = (double)oy, dz = (double)oz;
-                    const double over = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
-                    d[j] = (float)__dadd_rn((double)d[j], __dsqrt_rn(over));
+        return moved;
+    };
+    auto finish = [&](const float4& p, const float mr_i, float (&d)[8], const float (&vv)[6], const bool some_outside) {
+            if (some_outside) {
+                const float vx[2] = {vv[0], vv[1]}, vy[2] = {vv[2], vv[3]}, vz[2] = {vv[4], vv[5]};
+                // the overshoot per axis as LDT::Distance forms it: mn - v below the box, v - mx above it, else 0
+                float ovx[2], ovy[2], ovz[2];
+    #pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    ovx[s] = fmaxf(fmaxf(__fsub_rn(e.mnx, vx[s]), __fsub_rn(vx[s], mxx)), 0.f);
+                    ovy[s] = fmaxf(fmaxf(__fsub_rn(e.mny, vy[s]), __fsub_rn(vy[s], mxy)), 0.f);
+                    ovz[s] = fmaxf(fmaxf(__fsub_rn(e.mnz, vz[s]), __fsub_rn(vz[s], mxz)), 0.f);
+                }
+    #pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float ox = ovx[j & 1], oy = ovy[j >> 1 & 1], oz = ovz[j >> 2];
+                    if (ox != 0.f || oy != 0.f || oz != 0.f) {
+                        const double dx = (double)ox, dy = (double)oy, dz = (double)oz;
+                        const double over = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                        d[j] = (float)__dadd_rn((double)d[j], __dsqrt_rn(over));
+                    }
                 }
             }
+            // (mr_i is 0 without a level: d - 0 is d; two children at a time, for the packed float instructions)
+    #pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                v2f dj = v2f{d[j], d[j + 1]} - mr_i;
+                dj = v2f{fmaxf(dj.x, 0.f), fmaxf(dj.y, 0.f)};
+                if (mindis) { mindis[(size_t)(first + j) * n + __float_as_int(p.w)] = dj.x; mindis[(size_t)(first + j + 1) * n + __float_as_int(p.w)] = dj.y; }
+                const v2f sq = dj * dj;
+                ub[j] += (double)sq.x; ub[j + 1] += (double)sq.y;
+                v2f dis = dj - maxTransDis;
+                dis = v2f{fmaxf(dis.x, 0.f), fmaxf(dis.y, 0.f)};      // a term that is not positive adds +0, which leaves the sum as it is
+                const v2f sq2 = dis * dis;
+                lb[j] += (double)sq2.x; lb[j + 1] += (double)sq2.y;
+            }
+    };
+    if (AHEAD <= 1) {
+        size_t i = lo + threadIdx.x;
+        float4 p_next = i < hi ? data[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float mr_next = mr && i < hi ? mr[i] : 0.f;
+        for (; i < hi; i += blockDim.x) {
+            const float4 p = p_next;
+            const float mr_i = mr_next;
+            if (i + blockDim.x < hi) { p_next = data[i + blockDim.x]; if (mr) mr_next = mr[i + blockDim.x]; }
+            float d[8], vv[6];
+            const bool moved = lookup(p, d, vv);
+            finish(p, mr_i, d, vv, __any(moved));
         }
+    } else {
+        // Few workgroups in the launch (the last running searches of a step): the time is that of one thread's chain of
+        // points, each a rotation, eight reads and the sums. AHEAD points are looked up together and added in order.
+        constexpr int U = AHEAD > 1 ? AHEAD : 1;
+        for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += (size_t)U * blockDim.x) {
+            float4 p[U];
+            float mr_i[U], d[U][8], vv[U][6];
+            bool live[U], moved[U];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            float dj = d[j];
-            if (mr) dj -= mr_i;
-            if (dj < 0) dj = 0;
-            if (mindis) mindis[(size_t)(first + j) * n + __float_as_int(p.w)] = dj;
-            ub[j] += (double)(dj * dj);
-            const float dis = fmaxf(dj - maxTransDis, 0.f);      // a term that is not positive adds +0, which leaves the sum as it is
-            lb[j] += (double)(dis * dis);
+            for (int u = 0; u < U; u++) {
+                const size_t i = i0 + (size_t)u * blockDim.x;
+                live[u] = i < hi;
+                p[u] = live[u] ? data[i] : make_float4(0.f, 0.f, 0.f, 0.f);     // (a point that is not there is looked up at the origin and left out of the sums)
+                mr_i[u] = mr && live[u] ? mr[i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) moved[u] = lookup(p[u], d[u], vv[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool some_outside = __any(moved[u] && live[u]);
+                if (live[u]) finish(p[u], mr_i[u], d[u], vv[u], some_outside);
+            }
         }
     }
     // The sixteen sums of the wave by one butterfly instead of sixteen: at each of the first four steps a lane hands the
@@ -341,7 +397,7 @@ __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __re
 // The same over a list of parent cubes whose length is only known on the device (*count, written by the kernel that
 // made the list): workgroup (x, y) takes parents x, x + gridDim.x, ... of slice y, so a grid sized for an earlier,
 // longer list does no harm.
-template <int BRICKS>
+template <int BRICKS, int AHEAD>
 __global__ __launch_bounds__(256) void k_bnb_eval8_list(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
                                                         const icpx_bnb_item* __restrict__ parents, const int* __restrict__ count, int nsplit,
                                                         double* __restrict__ partials) {
@@ -349,7 +405,7 @@ __global__ __launch_bounds__(256) void k_bnb_eval8_list(EdtView e, const float4*
     __shared__ double sm8[16][4];
     const int cnt = *count;
     for (int a = (int)blockIdx.x; a < cnt; a += (int)gridDim.x) {
-        bnb_eval8_body<BRICKS, true>(e, data, n, maxrot, parents, 8 * cnt, nsplit, partials, nullptr, a, (int)blockIdx.y, sm, sm8);
+        bnb_eval8_body<BRICKS, true, AHEAD>(e, data, n, maxrot, parents, 8 * cnt, nsplit, partials, nullptr, a, (int)blockIdx.y, sm, sm8);
         __syncthreads();                     // the sums of this parent have been read before the next one's are written
     }
 }
@@ -930,7 +986,9 @@ extern "C" int icpx_bnb_search_run(icpx_ctx* ctx, const icpx_bnb_search* searche
     ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sb[7].p, ctx->bnb_pin, n * sizeof(icpx_bnb_search), hipMemcpyHostToDevice, ctx->stream));
     ICPX_CHECK_HIP(ctx, hipMemsetAsync(cnt, 0, (ICPX_SEARCH_MAX_STEPS + 1) * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_search_start, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sb[7].as<icpx_bnb_search>(), (int)n, st, active, parents, cnt);
-    auto eval = !ctx->edt_bricks_ready ? k_bnb_eval8_list<0> : ctx->edt_fbricks_ready ? k_bnb_eval8_list<2> : k_bnb_eval8_list<1>;
+    auto eval = !ctx->edt_bricks_ready ? k_bnb_eval8_list<0, 1> : ctx->edt_fbricks_ready ? k_bnb_eval8_list<2, 1> : k_bnb_eval8_list<1, 1>;
+    // (with few searches left a step lasts as long as one thread's chain of points: several points in flight per thread then)
+    auto eval_few = ctx->edt_fbricks_ready ? k_bnb_eval8_list<2, 4> : eval;
     const EdtView view = edt_view(ctx);
     size_t running = n;            // an upper bound on the searches still running
     int step = 0;
@@ -943,7 +1001,7 @@ extern "C" int icpx_bnb_search_run(icpx_ctx* ctx, const icpx_bnb_search* searche
         const unsigned gx = (unsigned)std::min<size_t>(running, (size_t)ctx->num_cus * 4), gs = (unsigned)std::min<size_t>(running, (size_t)ctx->num_cus * 8);
         for (; step < upto; step++) {
             const int in = step & 1, out = in ^ 1;
-            hipLaunchKernelGGL(eval, dim3(gx, (unsigned)nsplit), dim3(256), 0, ctx->stream, view, ctx->data_pts.as<float4>(), nd, ctx->maxrot.as<float>(),
+            hipLaunchKernelGGL(running <= (size_t)ctx->search_few ? eval_few : eval, dim3(gx, (unsigned)nsplit), dim3(256), 0, ctx->stream, view, ctx->data_pts.as<float4>(), nd, ctx->maxrot.as<float>(),
                                parents + (size_t)in * n, cnt + step, nsplit, sb[5].as<double>());
             hipLaunchKernelGGL(k_search_step, dim3(gs), dim3(64), 0, ctx->stream, st, sb[1].as<float4>(), sb[2].as<float>(), sb[5].as<double>(), nsplit,
                                active + (size_t)in * n, cnt + step, active + (size_t)out * n, cnt + step + 1, parents + (size_t)out * n, sse_thresh);

@@ -129,6 +129,7 @@ struct icpx_ctx {
     double* bnb_scratch = nullptr;   // this GPU's address of the fixed partial-sum area of icpx_bnb_eval_noalloc (resolved at icpx_create)
     BnbSlot bnb_slot[ICPX_BNB_SLOTS];
     DevBuf search_buf[8];        // icpx_bnb_search_run: states, queues (cubes, bounds), lists, parent records, partial sums, list lengths, in / out records
+    int search_few = 128;        // with at most this many searches running, the bound kernel keeps four points in flight per thread (ICPX_SEARCH_FEW)
     int search_max_steps = 4096; // steps after which icpx_bnb_search_run gives up on the searches still running (ICPX_SEARCH_STEPS lowers it)
     int search_lot = 4, search_lot_max = 16;   // steps enqueued between two looks at the list length: first lot, and the most (ICPX_SEARCH_LOT=first,most)
     void* bnb_pin = nullptr;     // pinned host staging of a bound batch: the items going up, then ub / lb coming down

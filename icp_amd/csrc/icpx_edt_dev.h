@@ -42,6 +42,22 @@ static __device__ __forceinline__ EdtAxis edt_axis_begin(float v, float mn, floa
     r.near = !(fabsf(r.q - rintf(r.q)) > r.q * 1e-6f);
     return r;
 }
+// The same without the overshoot (`moved` says whether there is one, for the caller to form it where needed), and with a
+// cheaper test for `near`: the fraction of the product lies within `eps` of 0 or 1, eps >= 1e-6 times the largest
+// quotient (the number of cells per axis), so `near` is set whenever edt_axis_begin sets it.
+static __device__ __forceinline__ EdtAxis edt_axis_begin_inside(float v, float mn, float mx, float inv, float eps, bool& moved) {
+    EdtAxis r;
+    r.over = 0.f;
+    const float c = fminf(fmaxf(v, mn), mx);
+    moved = c != v;                 // the coordinate lay outside [mn, mx]
+    v = c;
+    r.a = __fsub_rn(v, mn);
+    r.q = __fmul_rn(r.a, inv);
+    r.near = !(fabsf(__builtin_amdgcn_fractf(r.q) - 0.5f) < 0.5f - eps);
+    return r;
+}
+// (a >= 0 and so is the quotient: only the upper end needs clamping)
+static __device__ __forceinline__ unsigned edt_axis_cell_inside(const EdtAxis& r, int div) { return (unsigned)min((int)r.q, div - 1); }
 static __device__ __forceinline__ void edt_axis_exact(EdtAxis& r, float cell) {
     if (r.near) r.q = __fdiv_rn(r.a, cell);
 }

@@ -97,7 +97,9 @@ def test_eight_items_per_workgroup_gives_the_same_bits(oracle, bunny000, bun270,
     # a family whose members differ in level is no family: items 24..31 share everything but the level of the last one
     levels[31] = 4
     got = {}
-    for name, group_min, bricks in (("eight", "0", "1"), ("eight, plain grid", "0", "0"), ("one", "1000000000", "1")):
+    # ICPX_BNB_BRICKS: what the eight-item kernel reads (2, the default: distances as floats in bricks of 4 x 4 x 4 voxels;
+    # 1: squared distances as 16-bit values in such bricks; 0: the [x][y][z] grid)
+    for name, group_min, bricks in (("eight", "0", "2"), ("eight, 16-bit bricks", "0", "1"), ("eight, plain grid", "0", "0"), ("one", "1000000000", "1")):
         monkeypatch.setenv("ICPX_BNB_GROUP_MIN", group_min)
         monkeypatch.setenv("ICPX_BNB_BRICKS", bricks)
         ctx = Context(0)
@@ -110,7 +112,7 @@ def test_eight_items_per_workgroup_gives_the_same_bits(oracle, bunny000, bun270,
             got[name] = ctx.bnb_eval(items, want_mindis=True) + ctx.bnb_eval(items)[:2]
         finally:
             ctx.close()
-    for other in ("eight, plain grid", "one"):
+    for other in ("eight, 16-bit bricks", "eight, plain grid", "one"):
         for a, b in zip(got["eight"], got[other]):
             assert np.array_equal(a, b), other
     assert np.array_equal(got["eight"][0], got["eight"][3]) and np.array_equal(got["eight"][1], got["eight"][4])   # with and without the per-point output
@@ -126,9 +128,10 @@ def test_eight_items_per_workgroup_gives_the_same_bits(oracle, bunny000, bun270,
 
 
 def test_brick_copy_of_the_grid_far_from_the_surface(oracle, monkeypatch):
-    """The bound kernel reads 16-bit copies of the squared distances and goes back to the 32-bit grid where a value does
-    not fit: a thin target in a 400^3 grid has voxels more than 255 cells away. Same bits as the kernel that only knows
-    the 32-bit grid, and per-point distances equal to the oracle's."""
+    """The bound kernel reads brick copies of the grid: the distances as floats, or (ICPX_BNB_BRICKS=1) the squared
+    distances as 16-bit values, going back to the 32-bit grid where a value does not fit: a thin target in a 400^3 grid
+    has voxels more than 255 cells away. Same bits as the kernel that only knows the 32-bit grid, and per-point distances
+    equal to the oracle's."""
     from icp_amd.api import Context
     rng = np.random.default_rng(5)
     target = np.c_[np.linspace(-0.5, 0.5, 200), rng.normal(0, 1e-3, 200), rng.normal(0, 1e-3, 200)].astype(np.float32)
@@ -136,8 +139,9 @@ def test_brick_copy_of_the_grid_far_from_the_surface(oracle, monkeypatch):
     R = oracle.goicp_rotmat(np.array([0.05, -0.02, 0.03], np.float32)).reshape(9)
     cubes = np.concatenate([_families(np.random.default_rng(6), 1, [0.125]) * np.float32([0.05, 0.05, 0.05, 1]), _families(np.random.default_rng(7), 1, [0.5]) * np.float32([0.1, 0.1, 0.1, 1])])
     got = {}
-    for name, group_min in (("eight", "0"), ("one", "1000000000")):
+    for name, group_min, bricks in (("eight", "0", "2"), ("eight, 16-bit bricks", "0", "1"), ("one", "1000000000", "2")):
         monkeypatch.setenv("ICPX_BNB_GROUP_MIN", group_min)
+        monkeypatch.setenv("ICPX_BNB_BRICKS", bricks)
         ctx = Context(0)
         try:
             ctx.set_target(target)
@@ -152,8 +156,9 @@ def test_brick_copy_of_the_grid_far_from_the_surface(oracle, monkeypatch):
                 assert np.array_equal(a, b)
         finally:
             ctx.close()
-    for a, b in zip(got["eight"], got["one"]):
-        assert np.array_equal(a, b)
+    for other in ("eight, 16-bit bricks", "one"):
+        for a, b in zip(got["eight"], got[other]):
+            assert np.array_equal(a, b), other
     assert int(sq.max()) > 65535
     rotated = oracle.goicp_rotate(R.reshape(3, 3), data)
     _, _, rmd = oracle.goicp_bounds(rotated, cubes[:8], sq, info["min"], info["cell"], maxrot=None, want_mindis=True)
