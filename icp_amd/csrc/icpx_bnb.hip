@@ -158,7 +158,19 @@ static __device__ __forceinline__ bool same_bits(float a, float b) { return __fl
 // operations on the same operands as there and added in the same order, so the bounds are the same bits.
 // PARENTS: `items` holds one record per family, the parent cube, and the eight children are formed here as the search
 // forms them (src/GoIcp.cpp:378-390: w' = w / 2, corner + (0 or 1) w' per axis, in float).
-template <int BRICKS, bool PARENTS, int AHEAD = 1>      // BRICKS: 0 the [x][y][z] grid, 1 the 16-bit bricks, 2 the float bricks
+// A partial sum on its way out. AGENT: for a reader in another workgroup of the same launch, which may run on another
+// XCD with an L2 of its own: an atomic exchange at agent scope is performed where all XCDs see it, and its returned
+// value says that it has been (a plain store followed by a fence costs a write-back of the whole L2 per workgroup:
+// six times the run time of the search).
+template <bool AGENT>
+static __device__ __forceinline__ void bnb_put(double* where, double v) {
+    if (AGENT) {
+        const double old = __hip_atomic_exchange(where, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" :: "v"(old));           // the value is waited for
+    } else *where = v;
+}
+
+template <int BRICKS, bool PARENTS, int AHEAD = 1, bool AGENT_OUT = false>      // BRICKS: 0 the [x][y][z] grid, 1 the 16-bit bricks, 2 the float bricks
 static __device__ __forceinline__ void bnb_eval8_body(const EdtView& e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
                                                       const icpx_bnb_item* __restrict__ items, int nitems, int nsplit, double* __restrict__ partials,
                                                       float* __restrict__ mindis, const int block, const int split, double (*sm)[4], double (*sm8)[4]) {
@@ -173,7 +185,7 @@ static __device__ __forceinline__ void bnb_eval8_body(const EdtView& e, const fl
         ty[0] = it.y + half; ty[1] = (it.y + it.w) + half;
         tz[0] = it.z + half; tz[1] = (it.z + it.w) + half;
         if (it.level >= ICPX_MAXROTLEVEL) {    // a level beyond the table: NaN bounds, as in the one-item kernel
-            if (threadIdx.x < 16) partials[((size_t)(first + (threadIdx.x >> 1)) * nsplit + split) * 2 + (threadIdx.x & 1)] = (double)NAN;
+            if (threadIdx.x < 16) bnb_put<AGENT_OUT>(&partials[((size_t)(first + (threadIdx.x >> 1)) * nsplit + split) * 2 + (threadIdx.x & 1)], (double)NAN);
             return;
         }
     } else {
@@ -381,7 +393,7 @@ static __device__ __forceinline__ void bnb_eval8_body(const EdtView& e, const fl
     __syncthreads();
     if (threadIdx.x < 16) {
         const double v = (sm8[threadIdx.x][0] + sm8[threadIdx.x][1]) + (sm8[threadIdx.x][2] + sm8[threadIdx.x][3]);
-        partials[((size_t)(first + (threadIdx.x >> 1)) * nsplit + split) * 2 + (threadIdx.x & 1)] = v;
+        bnb_put<AGENT_OUT>(&partials[((size_t)(first + (threadIdx.x >> 1)) * nsplit + split) * 2 + (threadIdx.x & 1)], v);
     }
 }
 
@@ -392,22 +404,6 @@ __global__ __launch_bounds__(256) void k_bnb_eval8(EdtView e, const float4* __re
     __shared__ double sm[2][4];
     __shared__ double sm8[16][4];
     bnb_eval8_body<BRICKS, PARENTS>(e, data, n, maxrot, items, nitems, nsplit, partials, mindis, (int)blockIdx.x, (int)blockIdx.y, sm, sm8);
-}
-
-// The same over a list of parent cubes whose length is only known on the device (*count, written by the kernel that
-// made the list): workgroup (x, y) takes parents x, x + gridDim.x, ... of slice y, so a grid sized for an earlier,
-// longer list does no harm.
-template <int BRICKS, int AHEAD>
-__global__ __launch_bounds__(256) void k_bnb_eval8_list(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
-                                                        const icpx_bnb_item* __restrict__ parents, const int* __restrict__ count, int nsplit,
-                                                        double* __restrict__ partials) {
-    __shared__ double sm[2][4];
-    __shared__ double sm8[16][4];
-    const int cnt = *count;
-    for (int a = (int)blockIdx.x; a < cnt; a += (int)gridDim.x) {
-        bnb_eval8_body<BRICKS, true, AHEAD>(e, data, n, maxrot, parents, 8 * cnt, nsplit, partials, nullptr, a, (int)blockIdx.y, sm, sm8);
-        __syncthreads();                     // the sums of this parent have been read before the next one's are written
-    }
 }
 
 // The eight children of every parent cube as items of their own, for batches too small to fill the chip eight items
@@ -843,97 +839,129 @@ __global__ void k_search_start(const icpx_bnb_search* __restrict__ in, int n, Se
     parents[i] = it;
 }
 
-// One step of the running searches: workgroup (one wave) a takes the bounds of the eight children of active search a.
-__global__ __launch_bounds__(64) void k_search_step(SearchState* __restrict__ states, float4* __restrict__ heap_cube, float* __restrict__ heap_lb,
-                                                    const double* __restrict__ partials, int nsplit, const int* __restrict__ active_in,
-                                                    const int* __restrict__ cnt_in, int* __restrict__ active_out, int* __restrict__ cnt_out,
-                                                    icpx_bnb_item* __restrict__ parents_out, float sse_thresh) {
-    __shared__ float4 h_cube[ICPX_SEARCH_HEAP_CAP];
-    __shared__ float h_lb[ICPX_SEARCH_HEAP_CAP];
-    __shared__ float s_bound[16];
-    __shared__ int s_n;
-    const int lane = (int)threadIdx.x;
-    const int cnt = *cnt_in;
-    for (int a = (int)blockIdx.x; a < cnt; a += (int)gridDim.x) {
-        const int sid = active_in[a];
-        if (lane < 16) {
-            // child lane >> 1, ub (even lanes) or lb (odd): the slices in order from zero, as k_bnb_reduce adds them
-            double v = 0.0;
-            for (int sl = 0; sl < nsplit; sl++) v += partials[((size_t)(a * 8 + (lane >> 1)) * nsplit + sl) * 2 + (lane & 1)];
-            s_bound[lane] = (float)v;
+// One step of one running search, by the workgroup that holds the last of its slices: the bounds of the eight children
+// of active search a are summed over the slices and taken as the loop of GoIcp::innerBnB takes them (src/GoIcp.cpp:432-452),
+// the search's queue moves, and the cube taken next goes into the list of the following step.
+// Called by all threads of the workgroup; h_cube / h_lb / s_bound / s_n: its scratch in LDS. The partial sums were
+// written by other workgroups of this launch, on any XCD: they are read past the caches (agent-scope loads) after the
+// fence that follows the arrival count.
+static __device__ __forceinline__ void search_step_one(const int a, SearchState* __restrict__ states, float4* __restrict__ heap_cube, float* __restrict__ heap_lb,
+                                                       const double* partials, int nsplit, const int* __restrict__ active_in,
+                                                       int* __restrict__ active_out, int* __restrict__ cnt_out, icpx_bnb_item* __restrict__ parents_out,
+                                                       float sse_thresh, float4* h_cube, float* h_lb, float* s_bound, int* s_n) {
+    const int tid = (int)threadIdx.x, nthreads = (int)blockDim.x;
+    const int sid = active_in[a];
+    if (tid < 16) {
+        // child tid >> 1, ub (even) or lb (odd): the slices in order from zero, as k_bnb_reduce adds them
+        double v = 0.0;
+        for (int sl = 0; sl < nsplit; sl++)
+            v += __hip_atomic_load(&partials[((size_t)(a * 8 + (tid >> 1)) * nsplit + sl) * 2 + (tid & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_bound[tid] = (float)v;
+    }
+    const int n0 = states[sid].count;
+    const size_t hbase = (size_t)sid * ICPX_SEARCH_HEAP_CAP;
+    for (int k = tid; k < n0; k += nthreads) { h_cube[k] = heap_cube[hbase + k]; h_lb[k] = heap_lb[hbase + k]; }
+    __syncthreads();
+    if (tid == 0) {
+        SearchState s = states[sid];
+        int n = n0;
+        s.pops++;
+        const float w2 = s.parent[3] * 0.5f;              // (float)(w / 2.0), exact
+        for (int j = 0; j < 8 && !s.done; j++) {
+            const float cx = s.parent[0] + (float)(j & 1) * w2, cy = s.parent[1] + (float)(j >> 1 & 1) * w2, cz = s.parent[2] + (float)(j >> 2 & 1) * w2;
+            const float u = s_bound[2 * j], l = s_bound[2 * j + 1];
+            if (u < s.opt) { s.opt = u; s.best[0] = cx; s.best[1] = cy; s.best[2] = cz; s.best[3] = w2; s.have_best = 1; }
+            if (l >= s.opt) continue;
+            if ((double)s.opt - (double)l < (double)sse_thresh) { s.done = 1; continue; }
+            if (n >= ICPX_SEARCH_HEAP_CAP) { s.done = 1; s.status = 1; continue; }
+            // push_heap: the new cube moves up past every parent with a greater lower bound
+            int hole = n++;
+            while (hole > 0) {
+                const int par = (hole - 1) / 2;
+                if (!(h_lb[par] > l)) break;
+                h_cube[hole] = h_cube[par]; h_lb[hole] = h_lb[par];
+                hole = par;
+            }
+            h_cube[hole] = make_float4(cx, cy, cz, w2); h_lb[hole] = l;
         }
-        const int n0 = states[sid].count;
-        const size_t hbase = (size_t)sid * ICPX_SEARCH_HEAP_CAP;
-        for (int k = lane; k < n0; k += 64) { h_cube[k] = heap_cube[hbase + k]; h_lb[k] = heap_lb[hbase + k]; }
-        __syncthreads();
-        if (lane == 0) {
-            SearchState s = states[sid];
-            int n = n0;
-            s.pops++;
-            const float w2 = s.parent[3] * 0.5f;              // (float)(w / 2.0), exact
-            for (int j = 0; j < 8 && !s.done; j++) {
-                const float cx = s.parent[0] + (float)(j & 1) * w2, cy = s.parent[1] + (float)(j >> 1 & 1) * w2, cz = s.parent[2] + (float)(j >> 2 & 1) * w2;
-                const float u = s_bound[2 * j], l = s_bound[2 * j + 1];
-                if (u < s.opt) { s.opt = u; s.best[0] = cx; s.best[1] = cy; s.best[2] = cz; s.best[3] = w2; s.have_best = 1; }
-                if (l >= s.opt) continue;
-                if ((double)s.opt - (double)l < (double)sse_thresh) { s.done = 1; continue; }
-                if (n >= ICPX_SEARCH_HEAP_CAP) { s.done = 1; s.status = 1; continue; }
-                // push_heap: the new cube moves up past every parent with a greater lower bound
-                int hole = n++;
+        if (!s.done && n == 0) s.done = 1;
+        if (!s.done) {
+            // pop_heap: the top leaves, the hole moves down along the children with the smaller lower bound (the left
+            // one when equal), and the last cube is pushed up from there
+            const float4 top = h_cube[0];
+            n--;
+            if (n > 0) {
+                const float4 vc = h_cube[n];
+                const float vl = h_lb[n];
+                const int len = n;
+                int hole = 0, child = 0;
+                while (child < (len - 1) / 2) {
+                    child = 2 * (child + 1);
+                    if (h_lb[child] > h_lb[child - 1]) child--;
+                    h_cube[hole] = h_cube[child]; h_lb[hole] = h_lb[child];
+                    hole = child;
+                }
+                if ((len & 1) == 0 && child == (len - 2) / 2) {
+                    child = 2 * (child + 1);
+                    h_cube[hole] = h_cube[child - 1]; h_lb[hole] = h_lb[child - 1];
+                    hole = child - 1;
+                }
                 while (hole > 0) {
                     const int par = (hole - 1) / 2;
-                    if (!(h_lb[par] > l)) break;
+                    if (!(h_lb[par] > vl)) break;
                     h_cube[hole] = h_cube[par]; h_lb[hole] = h_lb[par];
                     hole = par;
                 }
-                h_cube[hole] = make_float4(cx, cy, cz, w2); h_lb[hole] = l;
+                h_cube[hole] = vc; h_lb[hole] = vl;
             }
-            if (!s.done && n == 0) s.done = 1;
-            if (!s.done) {
-                // pop_heap: the top leaves, the hole moves down along the children with the smaller lower bound (the left
-                // one when equal), and the last cube is pushed up from there
-                const float4 top = h_cube[0];
-                n--;
-                if (n > 0) {
-                    const float4 vc = h_cube[n];
-                    const float vl = h_lb[n];
-                    const int len = n;
-                    int hole = 0, child = 0;
-                    while (child < (len - 1) / 2) {
-                        child = 2 * (child + 1);
-                        if (h_lb[child] > h_lb[child - 1]) child--;
-                        h_cube[hole] = h_cube[child]; h_lb[hole] = h_lb[child];
-                        hole = child;
-                    }
-                    if ((len & 1) == 0 && child == (len - 2) / 2) {
-                        child = 2 * (child + 1);
-                        h_cube[hole] = h_cube[child - 1]; h_lb[hole] = h_lb[child - 1];
-                        hole = child - 1;
-                    }
-                    while (hole > 0) {
-                        const int par = (hole - 1) / 2;
-                        if (!(h_lb[par] > vl)) break;
-                        h_cube[hole] = h_cube[par]; h_lb[hole] = h_lb[par];
-                        hole = par;
-                    }
-                    h_cube[hole] = vc; h_lb[hole] = vl;
-                }
-                s.parent[0] = top.x; s.parent[1] = top.y; s.parent[2] = top.z; s.parent[3] = top.w;
-                const int slot = atomicAdd(cnt_out, 1);
-                active_out[slot] = sid;
-                icpx_bnb_item it;
-                for (int k = 0; k < 9; k++) it.R[k] = s.R[k];
-                it.x = top.x; it.y = top.y; it.z = top.z; it.w = top.w; it.level = s.level;
-                parents_out[slot] = it;
-            }
-            s.count = n;
-            states[sid] = s;
-            s_n = s.done ? 0 : n;           // a finished search's queue is not read again
+            s.parent[0] = top.x; s.parent[1] = top.y; s.parent[2] = top.z; s.parent[3] = top.w;
+            const int slot = atomicAdd(cnt_out, 1);
+            active_out[slot] = sid;
+            icpx_bnb_item it;
+            for (int k = 0; k < 9; k++) it.R[k] = s.R[k];
+            it.x = top.x; it.y = top.y; it.z = top.z; it.w = top.w; it.level = s.level;
+            parents_out[slot] = it;
+        }
+        s.count = n;
+        states[sid] = s;
+        *s_n = s.done ? 0 : n;           // a finished search's queue is not read again
+    }
+    __syncthreads();
+    const int n1 = *s_n;
+    for (int k = tid; k < n1; k += nthreads) { heap_cube[hbase + k] = h_cube[k]; heap_lb[hbase + k] = h_lb[k]; }
+    __syncthreads();
+}
+
+// A step of all running searches in one launch. The list of cubes to bound (one per running search, *cnt_in of them,
+// written by the previous step) is worked off by workgroups (x, slice): x, x + gridDim.x, ... so that a grid sized for
+// an earlier, longer list does no harm. The workgroup that finishes the last slice of a cube (an arrival count per
+// list entry, back at zero afterwards) goes on with that search's step.
+template <int BRICKS, int AHEAD>
+__global__ __launch_bounds__(256) void k_search_eval_step(EdtView e, const float4* __restrict__ data, size_t n, const float* __restrict__ maxrot,
+                                                          const icpx_bnb_item* __restrict__ parents_in, const int* __restrict__ cnt_in, int nsplit,
+                                                          double* partials, int* __restrict__ arrive, SearchState* __restrict__ states,
+                                                          float4* __restrict__ heap_cube, float* __restrict__ heap_lb, const int* __restrict__ active_in,
+                                                          int* __restrict__ active_out, int* __restrict__ cnt_out, icpx_bnb_item* __restrict__ parents_out,
+                                                          float sse_thresh) {
+    __shared__ double sm[2][4];
+    __shared__ double sm8[16][4];
+    __shared__ float4 h_cube[ICPX_SEARCH_HEAP_CAP];
+    __shared__ float h_lb[ICPX_SEARCH_HEAP_CAP];
+    __shared__ float s_bound[16];
+    __shared__ int s_n, s_last;
+    const int cnt = *cnt_in;
+    for (int a = (int)blockIdx.x; a < cnt; a += (int)gridDim.x) {
+        bnb_eval8_body<BRICKS, true, AHEAD, true>(e, data, n, maxrot, parents_in, 8 * cnt, nsplit, partials, nullptr, a, (int)blockIdx.y, sm, sm8);
+        __syncthreads();                     // this workgroup's partial sums are out (bnb_put) before its arrival is counted
+        if (threadIdx.x == 0) {
+            const int before = atomicAdd(&arrive[a], 1);
+            s_last = before == nsplit - 1;
+            if (s_last) arrive[a] = 0;       // (nobody else touches this count before the next launch)
         }
         __syncthreads();
-        const int n1 = s_n;
-        for (int k = lane; k < n1; k += 64) { heap_cube[hbase + k] = h_cube[k]; heap_lb[hbase + k] = h_lb[k]; }
-        __syncthreads();
+        if (s_last) {                        // the same in all threads
+            search_step_one(a, states, heap_cube, heap_lb, partials, nsplit, active_in, active_out, cnt_out, parents_out, sse_thresh, h_cube, h_lb, s_bound, &s_n);
+        }
     }
 }
 
@@ -972,7 +1000,7 @@ extern "C" int icpx_bnb_search_run(icpx_ctx* ctx, const icpx_bnb_search* searche
     ICPX_TRY(icpx_reserve(ctx, sb[3], 2 * n * sizeof(int)));
     ICPX_TRY(icpx_reserve(ctx, sb[4], 2 * n * sizeof(icpx_bnb_item)));
     ICPX_TRY(icpx_reserve(ctx, sb[5], n * 8 * (size_t)nsplit * 2 * sizeof(double)));
-    ICPX_TRY(icpx_reserve(ctx, sb[6], (ICPX_SEARCH_MAX_STEPS + 1) * sizeof(int)));
+    ICPX_TRY(icpx_reserve(ctx, sb[6], (ICPX_SEARCH_MAX_STEPS + 1 + n) * sizeof(int)));       // list lengths per step, then the arrival counts
     ICPX_TRY(icpx_reserve(ctx, sb[7], n * std::max(sizeof(icpx_bnb_search), sizeof(icpx_bnb_found))));
     SearchState* st = sb[0].as<SearchState>();
     int* active = sb[3].as<int>();
@@ -984,11 +1012,12 @@ extern "C" int icpx_bnb_search_run(icpx_ctx* ctx, const icpx_bnb_search* searche
     int* pin_cnt = reinterpret_cast<int*>(static_cast<char*>(ctx->bnb_pin) + io_bytes);
     std::memcpy(ctx->bnb_pin, searches, n * sizeof(icpx_bnb_search));
     ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sb[7].p, ctx->bnb_pin, n * sizeof(icpx_bnb_search), hipMemcpyHostToDevice, ctx->stream));
-    ICPX_CHECK_HIP(ctx, hipMemsetAsync(cnt, 0, (ICPX_SEARCH_MAX_STEPS + 1) * sizeof(int), ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipMemsetAsync(cnt, 0, (ICPX_SEARCH_MAX_STEPS + 1 + n) * sizeof(int), ctx->stream));
+    int* arrive = cnt + ICPX_SEARCH_MAX_STEPS + 1;
     hipLaunchKernelGGL(k_search_start, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sb[7].as<icpx_bnb_search>(), (int)n, st, active, parents, cnt);
-    auto eval = !ctx->edt_bricks_ready ? k_bnb_eval8_list<0, 1> : ctx->edt_fbricks_ready ? k_bnb_eval8_list<2, 1> : k_bnb_eval8_list<1, 1>;
+    auto eval = !ctx->edt_bricks_ready ? k_search_eval_step<0, 1> : ctx->edt_fbricks_ready ? k_search_eval_step<2, 1> : k_search_eval_step<1, 1>;
     // (with few searches left a step lasts as long as one thread's chain of points: several points in flight per thread then)
-    auto eval_few = ctx->edt_fbricks_ready ? k_bnb_eval8_list<2, 4> : eval;
+    auto eval_few = ctx->edt_fbricks_ready ? k_search_eval_step<2, 4> : eval;
     const EdtView view = edt_view(ctx);
     size_t running = n;            // an upper bound on the searches still running
     int step = 0;
@@ -998,15 +1027,14 @@ extern "C" int icpx_bnb_search_run(icpx_ctx* ctx, const icpx_bnb_search* searche
     const int max_steps = std::min(ctx->search_max_steps, ICPX_SEARCH_MAX_STEPS);
     while (running > 0 && step < max_steps) {
         const int upto = std::min(step + lot, max_steps);
-        const unsigned gx = (unsigned)std::min<size_t>(running, (size_t)ctx->num_cus * 4), gs = (unsigned)std::min<size_t>(running, (size_t)ctx->num_cus * 8);
+        const unsigned gx = (unsigned)std::min<size_t>(running, (size_t)ctx->num_cus * 4);
         for (; step < upto; step++) {
             const int in = step & 1, out = in ^ 1;
             hipLaunchKernelGGL(running <= (size_t)ctx->search_few ? eval_few : eval, dim3(gx, (unsigned)nsplit), dim3(256), 0, ctx->stream, view, ctx->data_pts.as<float4>(), nd, ctx->maxrot.as<float>(),
-                               parents + (size_t)in * n, cnt + step, nsplit, sb[5].as<double>());
-            hipLaunchKernelGGL(k_search_step, dim3(gs), dim3(64), 0, ctx->stream, st, sb[1].as<float4>(), sb[2].as<float>(), sb[5].as<double>(), nsplit,
-                               active + (size_t)in * n, cnt + step, active + (size_t)out * n, cnt + step + 1, parents + (size_t)out * n, sse_thresh);
+                               parents + (size_t)in * n, cnt + step, nsplit, sb[5].as<double>(), arrive, st, sb[1].as<float4>(), sb[2].as<float>(),
+                               active + (size_t)in * n, active + (size_t)out * n, cnt + step + 1, parents + (size_t)out * n, sse_thresh);
         }
-        ICPX_TRY(icpx_launch_check(ctx, "k_search_step"));
+        ICPX_TRY(icpx_launch_check(ctx, "k_search_eval_step"));
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(pin_cnt, cnt + step, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         running = (size_t)*pin_cnt;

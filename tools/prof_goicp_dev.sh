@@ -11,13 +11,13 @@ f = glob.glob('$OUT/trace/*/*kernel_stats.csv')[0]
 for r in list(csv.DictReader(open(f)))[:5]:
     print(r['Name'][:60], r['Calls'], round(float(r['TotalDurationNs']) / 1e6, 3), 'ms, avg', r['AverageNs'], 'min', r['MinNs'], 'max', r['MaxNs'])
 t = glob.glob('$OUT/trace/*/*kernel_trace.csv')[0]
-rows = [r for r in csv.DictReader(open(t)) if 'k_bnb_eval8_list' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(t)) if 'k_search_eval_step' in r['Kernel_Name']]
 d = sorted(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows)
 import bisect
 for lim in (5000, 10000, 20000, 50000, 100000, 10**9):
     k = bisect.bisect_right(d, lim)
     print('eval launches up to', lim, 'ns:', k, 'sum ms', round(sum(d[:k]) / 1e6, 2))
-rows = [r for r in csv.DictReader(open(t)) if 'k_search_step' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(t)) if "k_search_start" in r["Kernel_Name"]]
 d = sorted(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows)
 for lim in (3000, 5000, 10000, 20000, 10**9):
     k = bisect.bisect_right(d, lim)
