@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--no-goicp", action="store_true", help="skip the Go-ICP bunny-270 extra")
     ap.add_argument("--goicp-lookahead", type=int, default=1, help="queued translation cubes whose children are evaluated ahead of time")
     ap.add_argument("--goicp-speculate", type=int, default=255, help="rotation cubes whose inner searches run ahead of time in the same launches")
+    ap.add_argument("--goicp-host-search", action="store_true", help="drive the inner searches from the host (a round trip per step) instead of running them on the device")
     ap.add_argument("--goicp-share-launches", action="store_true", help="several ranks: cut every bound batch into shares (a collective per launch) instead of dealing out the rotation cubes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo for CPU-side rehearsal)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -443,9 +444,10 @@ def main():
             # configs[3]: Go-ICP on the reference's bunny pair (model bunny000 = bun315/bun000, data bun315/bun270), both
             # clouds normalised isotropically into [-1,1]^3, DT 300^3, mse 1e-3. The 2 x 8 inner searches of a rotation cube
             # advance in lock-step, one launch per step (each starts from the optError of the moment the cube is popped,
-            # where the reference's one-after-the-other order lets a later search see an earlier one's improvement);
-            # `lookahead` and `speculate` only put more cubes into a launch, the decisions are those of lookahead = speculate
-            # = 0. With several ranks the rotation cubes of a step (the popped one and those searched ahead with it) are
+            # where the reference's one-after-the-other order lets a later search see an earlier one's improvement), on the
+            # device from start to end: queues and decisions stay there, the host enqueues steps (--goicp-host-search: a host
+            # round trip per step, as before). `speculate` (and, host-driven, `lookahead`) only put more cubes into a
+            # launch, the decisions are those of lookahead = speculate = 0. With several ranks the rotation cubes of a step (the popped one and those searched ahead with it) are
             # dealt out: each rank runs the inner searches of its cubes on its own GPU without communication, and one
             # all-reduce per step (RCCL on the context's stream, a few KB) spreads the results; every rank takes the
             # same decisions. --goicp-share-launches restores the earlier scheme (every launch cut into shares).
@@ -461,7 +463,7 @@ def main():
                     kw = dict(allreduce=allreduce_host)
                 go = GoIcp(gm, gd, mse=1e-3, dt_div=DIV, device=local, rank=rank, world=world, **kw)
                 go.options(batched=True, frontier_width=1, lookahead=args.goicp_lookahead, speculate=args.goicp_speculate,
-                           shard_cubes=not args.goicp_share_launches)
+                           shard_cubes=not args.goicp_share_launches, device_search=not args.goicp_host_search)
                 barrier(); t0 = time.perf_counter()
                 gr = go.registration()
                 barrier()
@@ -471,7 +473,9 @@ def main():
                     "epsilon": float(gr["sseThresh"]), "initial_sse": float(gr["initError"]), "icp_sse": float(gr["icpError"]),
                     "rotation_cubes": gr["rot_pops"], "bound_evaluations": gr["inner_evals"], "launches": gr["launches"],
                     "points": int(gd.shape[0]), "order": "inner searches of a rotation cube in lock-step (batched)",
-                    "lookahead": args.goicp_lookahead, "speculate": args.goicp_speculate,
+                    "inner_searches": "on the device (icpx_bnb_search_run)" if gr["search_steps"] else "driven by the host (icpx_bnb_submit per step)",
+                    "search_steps": gr["search_steps"],
+                    "lookahead": args.goicp_lookahead if not gr["search_steps"] else None, "speculate": args.goicp_speculate,
                     "searched_ahead_used": gr["spec_hits"], "searched_ahead_discarded": gr["spec_misses"],
                     "collectives": gr["collectives"],
                     "collective": "none" if world == 1 else
@@ -486,7 +490,10 @@ def main():
         try:
             # the bound kernel by itself: 512 families of eight sibling translation cubes (4 096 cubes) under random
             # rotations, lower-bound form at rotation level 3, against the full data cloud; events on the stream it runs on.
-            # Algorithmic bytes: 16 B per data point once per family + the 2-byte gather per (cube, point).
+            # Algorithmic bytes: 16 B per data point once per family + the 4-byte gather per (cube, point) (the distance as
+            # a float out of the brick copy of the grid). What bounds the kernel is neither HBM nor the vector units but the
+            # rate at which the L1 takes lane addresses (one a clock per CU; the 64 points of a wave fall into some 39
+            # different voxels per child cube): l1_accesses_per_clk_cu_offline, from the counters of a full Go-ICP run.
             if not args.no_goicp:
                 import ctypes as C
                 from icp_amd.host import normalize_goicp
@@ -506,7 +513,7 @@ def main():
                         cubes.append([x + (j & 1) * w / 2, y + (j >> 1 & 1) * w / 2, z + (j >> 2 & 1) * w / 2, w / 2])
                 items = ctx4.make_items(Rs, np.asarray(cubes, np.float32), levels)
                 nit = len(items)
-                ctx4.bnb_eval(items)                                   # also makes the 16-bit brick copy of the grid
+                ctx4.bnb_eval(items)                                   # also makes the brick copies of the grid
                 raw = np.frombuffer(C.string_at(C.addressof(items), C.sizeof(items)), np.uint8).copy()
                 items_dev = torch.from_numpy(raw).to(dev)
                 out_dev = torch.zeros(2 * nit, dtype=torch.float64, device=dev)
@@ -519,17 +526,20 @@ def main():
                     times.append(e0.elapsed_time(e1))
                 bn_ms = float(np.median(times))
                 ndp = int(gd.shape[0])
-                alg_b = 2.0 * nit * ndp + 16.0 * ndp * fam
+                alg_b = 4.0 * nit * ndp + 16.0 * ndp * fam
                 pm = _newest_profile("r*_goicp_pmc.json") or {}
-                k8 = next((v for k, v in pm.items() if k.startswith("k_bnb_eval8") and isinstance(v, dict)), None)
-                roofline_bnb = {"bound": "valu issue (not hbm): see valu_issue_frac_offline", "kernel": "k_bnb_eval8 + k_bnb_reduce", "cubes": nit, "points": ndp,
+                k8 = next((v for k, v in pm.items() if (k.startswith("k_search_eval_step") or k.startswith("k_bnb_eval8")) and isinstance(v, dict)), None)
+                cyc = k8["GRBM_GUI_ACTIVE"] / 8.0 if k8 and k8.get("GRBM_GUI_ACTIVE") else None
+                roofline_bnb = {"bound": "L1 lane-address rate (not hbm): see l1_accesses_per_clk_cu_offline", "kernel": "k_bnb_eval8 + k_bnb_reduce", "cubes": nit, "points": ndp,
                                 "algorithmic_bytes_per_launch": alg_b, "avg_launch_ms": bn_ms, "achieved": alg_b / (bn_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_b / (bn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "lookups_per_s": nit * ndp / (bn_ms * 1e-3), "ns_per_cube": bn_ms * 1e6 / nit, "traffic": None,
                                 # vector instructions issued x 4 cycles over the cycles of all 1 024 SIMDs, from the counters of a full
                                 # Go-ICP run under rocprofv3 (offline evidence, profiles/)
-                                "valu_issue_frac_offline": (k8["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (k8["GRBM_GUI_ACTIVE"] / 8.0)
-                                                            if k8 and "SQ_INSTS_VALU" in k8 and k8.get("GRBM_GUI_ACTIVE") else None)}
+                                "valu_issue_frac_offline": (k8["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc if cyc and "SQ_INSTS_VALU" in k8 else None),
+                                # accesses the L1s of the 256 CUs took per clock and CU over the same run (1 is what an L1 can take)
+                                "l1_accesses_per_clk_cu_offline": (k8["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc
+                                                                   if cyc and "TCP_TOTAL_CACHE_ACCESSES_sum" in k8 else None)}
                 ctx4.close()
         except Exception as exc:
             import traceback; traceback.print_exc()

@@ -890,7 +890,7 @@ bool GoIcp::run_searches_device(const std::vector<Search*>& ss, std::vector<Sear
         dev->check(icpx_bnb_search_run(dev->ctx(), in.data(), in.size(), sseThresh, out.data(), &steps));
     }
     search_steps += steps;
-    launches += 2 * steps;
+    launches += steps;
     for (size_t i = 0; i < ss.size(); i++) {
         Search& s = *ss[i];
         inner_evals += 8LL * out[i].cubes;

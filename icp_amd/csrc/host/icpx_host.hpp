@@ -330,7 +330,7 @@ public:
     // Used when frontier_width is 1, the sums are the device's (not parity_sums) and no bound batch is shared between
     // ranks; lookahead, tail_lookahead and pipeline then have nothing to do. Decisions are those of the host loop.
     bool device_search = true;
-    long long search_steps = 0;   // steps the device searches of the last OuterBnB took (two launches each)
+    long long search_steps = 0;   // steps the device searches of the last OuterBnB took (one launch each)
     long long max_rot_pops = 0;   // 0 = unlimited
     // world > 1, batched mode. true (default): the rotation cubes of a step (the popped one and the `speculate` searched
     // ahead with it) are dealt out to the ranks; each rank runs the complete inner searches of its cubes on its own GPU

@@ -798,9 +798,10 @@ extern "C" int icpx_bnb_eval_noalloc(icpx_ctx* ctx, const icpx_bnb_item* items_d
 // lower bound, bound its eight children, record a better upper bound, queue the children that can still hold a better
 // pose, stop when a child's lower bound comes within the threshold of the best error or the queue runs dry. A rotation
 // cube needs two such searches per child cube and they are independent of each other, so many run side by side; a step
-// of all of them is one launch of the bound kernel over the list of cubes taken (one per running search) and one launch
-// of k_search_step, which sums each cube's slices, takes the eight bounds as the loop above does, keeps the search's
-// queue and writes the next list. The host only enqueues steps and looks at the length of the list now and then.
+// of all of them is one launch (k_search_eval_step): the bound kernel over the list of cubes taken, one per running
+// search, and, by the workgroup that finishes a cube's last slice, the step of that search: the slices summed, the eight
+// bounds taken as the loop above takes them, the search's queue moved, the cube taken next put on the following step's
+// list. The host only enqueues steps and looks at the length of the list now and then.
 //
 // The queue is the binary heap of std::priority_queue<TransNode> (operator<: lb greater, src/GoIcp.cpp:35-42), moved by the push_heap /
 // pop_heap steps of the GNU C++ library, because cubes of equal lower bound (the many with lb = 0 near the root) leave

@@ -1,4 +1,4 @@
-# Counter passes over the bound kernels of one full-size Go-ICP run (tools/goicp_sweep.py, default setting run twice);
+# Counter passes over the bound / search kernels of one full-size Go-ICP run (tools/goicp_sweep.py, default setting run twice);
 # prints per-kernel totals over all launches and writes them to gpurun_out/pmc_goicp/goicp_pmc.json.
 # usage: pmc_goicp.sh "<counters of pass 1>" "<counters of pass 2>" ...
 export TMPDIR=/tmp
@@ -17,7 +17,7 @@ res = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(out + "/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"\bk_bnb\w+", r["Kernel_Name"])
+        m = re.search(r"\bk_(bnb|search)\w+", r["Kernel_Name"])
         if not m: continue
         res[m.group(0)][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[m.group(0)][r["Counter_Name"]] += 1
