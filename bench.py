@@ -374,6 +374,22 @@ def main():
             extra["icp_1m_rot_err_deg"] = float(np.rad2deg(np.arccos(np.clip((np.trace(T[:3, :3] @ Tm[:3, :3]) - 1) / 2, -1, 1))))
             extra["nn_roofline_frac"] = (36.0 * n + 12.0 * n * world) * iters / el / 1e9 / (HBM_PEAK_GBS * world)
             extra["icp_1m_pass_ms"] = [round(x, 4) for x in pass_ms]
+            if world == 1:
+                # the same 30 iterations as one call (SingleThreadIcp::registration's loop on the device, icpx_icp_run: no
+                # round trip per iteration, the 3 x 3 problem solved by one GPU thread with the host classes' arithmetic),
+                # from the same start: the source is set again so that no pair of the run above is left
+                ctx2.set_source(torch.from_numpy(np.ascontiguousarray(src_all[lo:hi])).to(dev))
+                mt0 = tgt_s.astype(np.float64).sum(0) / n
+                torch.cuda.synchronize(); ctx2.sync()
+                t0 = time.perf_counter()
+                Td, _, _ = ctx2.icp_run(np.eye(4), iters, mt0)
+                el_dev = time.perf_counter() - t0
+                extra["icp_1m_iterations_per_s_host_driven"] = extra["icp_1m_iterations_per_s"]
+                extra["icp_1m_iterations_per_s"] = iters / el_dev
+                extra["nn_queries_per_s"] = n * iters / el_dev
+                extra["icp_1m_loop"] = "on the device (icpx_icp_run); icp_1m_pass_ms and roofline_nn are from the host-driven passes"
+                extra["icp_1m_device_loop_rot_err_deg"] = float(np.rad2deg(np.arccos(np.clip((np.trace(Td[:3, :3] @ Tm[:3, :3]) - 1) / 2, -1, 1))))
+                extra["nn_roofline_frac"] = (36.0 * n + 12.0 * n) * iters / el_dev / 1e9 / HBM_PEAK_GBS
             for _ in range(10):                   # ten more passes, converged by now: the steady state of the pass
                 T = icp_iter(T, n, ctx2)
             conv_ms = float(np.mean(pass_ms[-10:]))

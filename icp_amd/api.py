@@ -145,6 +145,16 @@ class Context:
         self._ck(self._lib.icpx_icp_step_trimmed(self._h, T.ctypes.data_as(C.c_void_p), int(keep), sums.ctypes.data_as(C.c_void_p)))
         return sums
 
+    def icp_run(self, T0, iterations, mean_tar):
+        """icpx_icp_run: `iterations` ICP iterations on the device without the host in between. Returns (finMat 4x4, the
+        running target mean, trace [iterations, 18]: curMat (16), residual after the update, residual before it)."""
+        T0 = np.ascontiguousarray(T0, np.float64).reshape(16)
+        mt = np.ascontiguousarray(mean_tar, np.float64).reshape(3).copy()
+        out = np.empty(16); trace = np.empty((max(iterations, 0), 18))
+        self._ck(self._lib.icpx_icp_run(self._h, T0.ctypes.data_as(C.c_void_p), int(iterations), mt.ctypes.data_as(C.c_void_p),
+                                        out.ctypes.data_as(C.c_void_p), trace.ctypes.data_as(C.c_void_p)))
+        return out.reshape(4, 4), mt, trace
+
     def icp_step_async(self, T, sums_dev):
         T = np.ascontiguousarray(T, np.float64).reshape(16)
         p, where = _ptr(sums_dev, np.float64, self)

@@ -2,6 +2,7 @@
 // through include/icpx.h; what stays here is what the reference also does serially on the host:
 // 3x3 SVD, 4x4 algebra, priority queues and the branch-and-bound decisions.
 #include "icpx_host.hpp"
+#include "../icpx_solve.h"
 #include "icpx_io.hpp"
 
 #include <algorithm>
@@ -21,91 +22,20 @@ namespace icp {
 
 // ---- small algebra ------------------------------------------------------------------------------------
 
+// The dense 3 x 3 / 4 x 4 arithmetic lives in icpx_solve.h, shared with the device-side registration loop.
 Matrix4d Matrix4d::operator*(const Matrix4d& o) const {
     Matrix4d r;
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            double a = 0;
-            for (int k = 0; k < 4; k++) a += m[4 * i + k] * o.m[4 * k + j];
-            r.m[4 * i + j] = a;
-        }
+    icpx_solve::mul4(m, o.m, r.m);
     return r;
 }
 
-static double det3(const Matrix3d& M) {
-    return M(0, 0) * (M(1, 1) * M(2, 2) - M(1, 2) * M(2, 1)) - M(0, 1) * (M(1, 0) * M(2, 2) - M(1, 2) * M(2, 0)) +
-           M(0, 2) * (M(1, 0) * M(2, 1) - M(1, 1) * M(2, 0));
-}
+static double det3(const Matrix3d& M) { return icpx_solve::det3(M.m); }
 
-// One-sided (Hestenes) Jacobi SVD of a 3x3 matrix: columns of W = A V are rotated pairwise until they
-// are orthogonal; singular values are their norms. Accurate to working precision without forming A^T A.
-void svd3(const Matrix3d& A, Matrix3d& U, double sig[3], Matrix3d& V) {
-    double W[3][3], Vv[3][3];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) { W[i][j] = A(i, j); Vv[i][j] = (i == j); }
-    for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0;
-        for (int p = 0; p < 2; p++)
-            for (int q = p + 1; q < 3; q++) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int i = 0; i < 3; i++) { alpha += W[i][p] * W[i][p]; beta += W[i][q] * W[i][q]; gamma += W[i][p] * W[i][q]; }
-                if (gamma == 0.0) continue;
-                off = std::max(off, std::fabs(gamma) / std::sqrt(std::max(alpha * beta, 1e-300)));
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
-                for (int i = 0; i < 3; i++) {
-                    const double wp = W[i][p], wq = W[i][q];
-                    W[i][p] = c * wp - s * wq; W[i][q] = s * wp + c * wq;
-                    const double vp = Vv[i][p], vq = Vv[i][q];
-                    Vv[i][p] = c * vp - s * vq; Vv[i][q] = s * vp + c * vq;
-                }
-            }
-        if (off < 1e-16) break;
-    }
-    double nrm[3];
-    int ord[3] = {0, 1, 2};
-    for (int j = 0; j < 3; j++) nrm[j] = std::sqrt(W[0][j] * W[0][j] + W[1][j] * W[1][j] + W[2][j] * W[2][j]);
-    std::sort(ord, ord + 3, [&](int a, int b) { return nrm[a] > nrm[b]; });
-    double u[3][3];
-    for (int j = 0; j < 3; j++) {
-        const int o = ord[j];
-        sig[j] = nrm[o];
-        for (int i = 0; i < 3; i++) { V(i, j) = Vv[i][o]; u[j][i] = W[i][o]; }
-    }
-    // Normalise U; complete it when the input is rank deficient.
-    const double tiny = 1e-14 * std::max(sig[0], 1e-300);
-    if (sig[0] > 0) for (int i = 0; i < 3; i++) u[0][i] /= sig[0]; else { u[0][0] = 1; u[0][1] = u[0][2] = 0; }
-    if (sig[1] > tiny) for (int i = 0; i < 3; i++) u[1][i] /= sig[1];
-    else {
-        int mI = 0;
-        for (int i = 1; i < 3; i++) if (std::fabs(u[0][i]) < std::fabs(u[0][mI])) mI = i;
-        double e[3] = {0, 0, 0}; e[mI] = 1;
-        const double d = u[0][mI];
-        double n = 0;
-        for (int i = 0; i < 3; i++) { u[1][i] = e[i] - d * u[0][i]; n += u[1][i] * u[1][i]; }
-        n = std::sqrt(n);
-        for (int i = 0; i < 3; i++) u[1][i] /= n;
-    }
-    const double cx[3] = {u[0][1] * u[1][2] - u[0][2] * u[1][1], u[0][2] * u[1][0] - u[0][0] * u[1][2], u[0][0] * u[1][1] - u[0][1] * u[1][0]};
-    if (sig[2] > tiny) {
-        const double d = cx[0] * u[2][0] + cx[1] * u[2][1] + cx[2] * u[2][2];
-        for (int i = 0; i < 3; i++) u[2][i] = (d < 0 ? -cx[i] : cx[i]);
-    } else for (int i = 0; i < 3; i++) u[2][i] = cx[i];
-    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) U(i, j) = u[j][i];
-}
+void svd3(const Matrix3d& A, Matrix3d& U, double sig[3], Matrix3d& V) { icpx_solve::svd3(A.m, U.m, sig, V.m); }
 
-// R = (U V^T)^T; when det R < 0 the last row of V^T is negated first (src/SingleThreadIcp.cpp:256-266).
 Matrix3d kabsch_rotation(const Matrix3d& H) {
-    Matrix3d U, V, R;
-    double s[3];
-    svd3(H, U, s, V);
-    auto make = [&](double sgn) {
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) R(i, j) = U(j, 0) * V(i, 0) + U(j, 1) * V(i, 1) + sgn * U(j, 2) * V(i, 2);
-    };
-    make(1.0);
-    if (det3(R) < 0) make(-1.0);
+    Matrix3d R;
+    icpx_solve::kabsch_rotation(H.m, R.m);
     return R;
 }
 
@@ -519,39 +449,16 @@ void SingleThreadIcp::kdtree_search() {
 
 void SingleThreadIcp::cal_covarance() {
     const double N = (double)Nd_global;
-    for (int c = 0; c < 3; c++) mean_tmpdata[c] = sums_[c] / N;
-    // The reference adds the matched target points onto the PREVIOUS mean before dividing
-    // (src/SingleThreadIcp.cpp:229-231); reproduced, because it moves the result by ~1e-4.
-    for (int c = 0; c < 3; c++) mean_tar[c] = (mean_tar[c] + sums_[3 + c]) / N;
-    // sum (p - pbar)(q - m)^T = sum p q^T - pbar (sum q)^T for any m, since sum (p - pbar) = 0.
-    const double denom = (double)(float)Nd_global;   // "/= (float)Nd", :244
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) Neighbour.covariance(r, c) = (sums_[6 + 3 * r + c] - mean_tmpdata[r] * sums_[3 + c]) / denom;
+    // means, the reference's carry-over of the previous target mean, "/= (float)Nd": icpx_solve::covariance
+    icpx_solve::covariance(sums_, N, (double)(float)Nd_global, mean_tar.v, mean_tmpdata.v, Neighbour.covariance.m);
     nn_mse_trace.push_back(sums_[15] / N);
 }
 
 Matrix4d& SingleThreadIcp::best_fit_transform() {
-    const Matrix3d R = kabsch_rotation(Neighbour.covariance);
-    T = Matrix4d::Identity();
-    for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) T(r, c) = R(r, c);
-        T(r, 3) = mean_tar[r] - (R(r, 0) * mean_tmpdata[0] + R(r, 1) * mean_tmpdata[1] + R(r, 2) * mean_tmpdata[2]);
-    }
+    double mse_after = 0;
+    icpx_solve::best_fit(Neighbour.covariance.m, mean_tar.v, mean_tmpdata.v, sums_, (double)Nd_global, T.m, &mse_after);
     T_trace.push_back(T);
-    // The residual the reference logs after applying T with the pairs it was fitted to ("each transform mse",
-    // src/SingleThreadIcp.cpp:281-288): sum |R p + t - q|^2 / Nd, from the same sums:
-    //   sum |Rp + t - q|^2 = sum |p - q|^2 + 2 tr(Spq) + N |t|^2 + 2 t.(R Sp) - 2 sum_ij R_ij Spq_ji - 2 t.Sq.
-    {
-        const double N = (double)Nd_global;
-        const double* Sp = sums_; const double* Sq = sums_ + 3; const double* Spq = sums_ + 6;
-        double tr = Spq[0] + Spq[4] + Spq[8], tt = 0, tRSp = 0, RS = 0, tSq = 0;
-        for (int i = 0; i < 3; i++) {
-            tt += T(i, 3) * T(i, 3);
-            tSq += T(i, 3) * Sq[i];
-            for (int j = 0; j < 3; j++) { tRSp += T(i, 3) * R(i, j) * Sp[j]; RS += R(i, j) * Spq[3 * j + i]; }
-        }
-        mse_trace.push_back((sums_[15] + 2 * tr + N * tt + 2 * tRSp - 2 * RS - 2 * tSq) / N);
-    }
+    mse_trace.push_back(mse_after);      // "each transform mse" (src/SingleThreadIcp.cpp:281-288)
     return T;
 }
 
@@ -561,6 +468,19 @@ ICP_res SingleThreadIcp::registration(Matrix4d& guess, const PointCloudTPtr& pDa
     mse_trace.clear();
     nn_mse_trace.clear();
     T_trace.clear();
+    if (device_loop && comm.world <= 1 && !keep_correspondences && max_iter > 0) {
+        // the whole loop on the device (icpx_icp_run): the same arithmetic, no round trip per iteration
+        ensure_target();
+        std::vector<double> trace(18 * (size_t)max_iter);
+        dev->check(icpx_icp_run(dev->ctx(), guess.m, max_iter, mean_tar.v, finMat.m, trace.data()));
+        for (int iter = 0; iter < max_iter; iter++) {
+            const double* t = &trace[18 * (size_t)iter];
+            std::memcpy(T.m, t, sizeof T.m);
+            T_trace.push_back(T);
+            mse_trace.push_back(t[16]);
+            nn_mse_trace.push_back(t[17]);
+        }
+    } else
     for (int iter = 0; iter < max_iter; iter++) {
         kdtree_search();
         cal_covarance();
@@ -1439,6 +1359,7 @@ void* icpxh_icp_new(int device, const float* src, size_t ns, const float* tgt, s
     return h;
 }
 void icpxh_icp_free(void* p) { delete (HIcp*)p; }
+int icpxh_icp_device_loop(void* p, int on) { ((HIcp*)p)->icp->device_loop = on != 0; return 0; }
 // world > 1: this handle holds one slice of the source; allreduce sums `n` host doubles over the ranks in place.
 int icpxh_icp_set_collective(void* p, int rank, int world, void (*allreduce)(double*, int)) {
     return guard([&] {

@@ -215,6 +215,11 @@ public:
     Matrix4d T;                    // last per-iteration transform
     Matrix4d finMat;               // accumulated transform applied to the source on the GPU
     Vector3d mean_tar, mean_tmpdata;
+    // registration() as one call of icpx_icp_run: the iterations follow each other on the GPU, the small dense part (means,
+    // covariance, SVD, update) done by one thread there with the arithmetic of cal_covarance / best_fit_transform (the same
+    // source compiled for both sides). One process, no correspondences wanted; mean_tmpdata and Neighbour.covariance, the
+    // last iteration's intermediates, are then not filled. false: the loop below, a round trip per iteration.
+    bool device_loop = true;
     bool keep_correspondences = false;   // fill Neighbour.pointsPARA every iteration (costs a device->host copy)
     std::vector<double> mse_trace;       // per iteration, sum |T p - q|^2 / Nd AFTER the update with the pairs it was fitted to: the value the reference logs (src/SingleThreadIcp.cpp:281-288)
     std::vector<double> nn_mse_trace;    // per iteration, sum |p - q|^2 / Nd BEFORE the update (the NN residual)

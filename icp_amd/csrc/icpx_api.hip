@@ -115,7 +115,7 @@ extern "C" void icpx_destroy(icpx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->tgt_xyz, &ctx->cell_start, &ctx->cell_count, &ctx->pyr_masks, &ctx->pyr_tab, &ctx->sorted_pts, &ctx->sort_keys_a, &ctx->sort_keys_b,
-                      &ctx->sort_vals_a, &ctx->sort_vals_b, &ctx->sort_tmp, &ctx->cand_tab, &ctx->cand_tmp, &ctx->src_pts, &ctx->nn_seed, &ctx->nn_pair, &ctx->walk_queue, &ctx->tile_counters, &ctx->partials, &ctx->sums,
+                      &ctx->sort_vals_a, &ctx->sort_vals_b, &ctx->sort_tmp, &ctx->cand_tab, &ctx->cand_tmp, &ctx->src_pts, &ctx->nn_seed, &ctx->nn_pair, &ctx->icp_loop, &ctx->walk_queue, &ctx->tile_counters, &ctx->partials, &ctx->sums,
                       &ctx->scratch_q, &ctx->scratch_idx, &ctx->scratch_d2, &ctx->scratch_f, &ctx->edt_bits,
                       &ctx->edt_rowlist, &ctx->edt_rowcnt, &ctx->edt_planelist, &ctx->edt_counters, &ctx->trim_keys_a, &ctx->trim_keys_b, &ctx->trim_vals_a, &ctx->trim_vals_b, &ctx->trim_p, &ctx->trim_idx, &ctx->edt_spill, &ctx->edt_plane,
                       &ctx->edt_sq, &ctx->edt_bricks, &ctx->edt_fbricks, &ctx->data_pts, &ctx->maxrot, &ctx->bnb_items, &ctx->bnb_partials,

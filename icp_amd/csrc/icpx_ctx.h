@@ -67,6 +67,7 @@ struct icpx_ctx {
     // ---- source cloud (ICP) ----------------------------------------------------------------------
     size_t ns = 0;
     DevBuf src_pts;          // ns x float4 {x, y, z, bits(original index)}, spatially sorted
+    DevBuf icp_loop;         // icpx_icp_run: the loop's state (accumulated transform, running target mean), the sums of a pass, the per-iteration trace
     DevBuf nn_pair;          // ns float4, by sorted source position: the target point (x, y, z, index bits) the source point was paired with by the last ICP pass, index bits -1 = none
     DevBuf nn_seed;          // ns int, by sorted source position: position in sorted_pts of the target point the source point was paired with by the last ICP pass, -1 = none
     DevBuf tile_counters;    // eight 64-bit counters, 64 B apart, that hand out the tiles of an ICP pass; never reset

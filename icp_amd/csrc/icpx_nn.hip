@@ -13,6 +13,7 @@
 // are one contiguous run). Queries of the ICP step are the source cloud in Morton order, so the 64 queries of a
 // wave lie in a few neighbouring cells.
 #include "icpx_ctx.h"
+#include "icpx_solve.h"
 
 #include <rocprim/device/device_scan.hpp>
 
@@ -702,11 +703,12 @@ __device__ __forceinline__ void icp_enqueue_open(unsigned long long pend, bool h
     if (solo) queue[base + (size_t)tiles_per_shard * 64 - 1 - (at_s + __popcll(m_solo & below))] = i;
 }
 
-__global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
+__global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_tile(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, const Mat34* __restrict__ Tdev, size_t nt,
                                                               int* __restrict__ idx_out, float4* __restrict__ pair, size_t tiles_per_group,
                                                               unsigned long long* __restrict__ counters, unsigned long long counter_base,
                                                               unsigned* __restrict__ queue, unsigned* __restrict__ qcount, unsigned tiles_per_shard,
                                                               unsigned* __restrict__ far_queue, unsigned long long* __restrict__ far_mask) {
+    if (Tdev) T = *Tdev;              // the transform as the previous pass of a device-side loop left it
     __shared__ float4 sw_pts[TILE_WAVES][TILE_CAP + 8];         // as four arrays of TILE_CAP words: x, y, z, slot number
     __shared__ int sw_first[TILE_WAVES][TILE_COLS];       // per column of the box: start of its run in the sorted points
     __shared__ int sw_pre[TILE_WAVES][TILE_COLS + 4];     // ... and the number of box points in the columns before it
@@ -986,10 +988,11 @@ __device__ __forceinline__ void greedy_candidate(const GridView& g, const unsign
 #ifdef ICPX_BALL_WPE
 __attribute__((amdgpu_waves_per_eu(ICPX_BALL_WPE, ICPX_BALL_WPE)))
 #endif
-__global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
+__global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, const Mat34* __restrict__ Tdev, size_t nt,
                                                               int* __restrict__ idx_out, float4* __restrict__ pair, const unsigned* __restrict__ far_queue,
                                                               const unsigned long long* __restrict__ far_mask, unsigned* __restrict__ queue,
                                                               unsigned* __restrict__ qcount, unsigned tiles_per_shard, unsigned many_factor, unsigned few_tiles) {
+    if (Tdev) T = *Tdev;              // the transform as the previous pass of a device-side loop left it
     __shared__ float sw_xyz[TILE_WAVES][4][TILE_CAP + 8];
     __shared__ int sw_first[TILE_WAVES][TILE_COLS];
     __shared__ int sw_pre[TILE_WAVES][TILE_COLS + 4];
@@ -1296,9 +1299,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_ball(GridView g, const 
 // and dealt to the workgroups in turn: the workgroups that are resident together work on one stretch of the cloud
 // (whose cells and pyramid nodes then stay in L2: spreading them over the whole cloud cost a third more time), and
 // over its life every workgroup gets groups from all over the cloud (how long a walk takes depends on where the query is).
-__global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __restrict__ src, Mat34 T, size_t nt, const unsigned* __restrict__ queue,
+__global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __restrict__ src, Mat34 T, const Mat34* __restrict__ Tdev, size_t nt, const unsigned* __restrict__ queue,
                                                   const unsigned* __restrict__ qcount, unsigned tiles_per_shard, int* __restrict__ idx_out,
                                                   float4* __restrict__ pair, size_t n_all) {
+    if (Tdev) T = *Tdev;              // the transform as the previous pass of a device-side loop left it
     __shared__ unsigned snode[NN_STACK * NN_OCTETS];
     __shared__ float slb[NN_STACK * NN_OCTETS];
     __shared__ unsigned s_loff[MAXLEV];
@@ -1353,8 +1357,9 @@ __global__ __launch_bounds__(256) void k_icp_walk(GridView g, const float4* __re
 // the chord's points (float distance first, the exact one for points the float value cannot rule out); the lanes'
 // results are reduced by (distance, index). Every point as near as the candidate lies in the ball, so the result is the
 // exact nearest point with the lowest index, as from the walk.
-__global__ __launch_bounds__(256) void k_icp_solo(GridView g, const float4* __restrict__ src, Mat34 T, size_t nt, const unsigned* __restrict__ queue,
+__global__ __launch_bounds__(256) void k_icp_solo(GridView g, const float4* __restrict__ src, Mat34 T, const Mat34* __restrict__ Tdev, size_t nt, const unsigned* __restrict__ queue,
                                                   const unsigned* __restrict__ qcount, unsigned tiles_per_shard, int* __restrict__ idx_out, float4* __restrict__ pair) {
+    if (Tdev) T = *Tdev;              // the transform as the previous pass of a device-side loop left it
     __shared__ unsigned s_count[WALK_SHARDS];
     if (threadIdx.x < WALK_SHARDS) s_count[threadIdx.x] = qcount[threadIdx.x * 16 + 3];
     __syncthreads();
@@ -1445,8 +1450,9 @@ __global__ __launch_bounds__(256) void k_icp_solo(GridView g, const float4* __re
 // Block-partial sums {p, q, p q^T, |p-q|^2} over the pairs in pair[]: lane l of a block adds the terms of point l of
 // its tiles in tile order and the lanes are summed by a fixed butterfly, so the sums depend on the pairs alone (not on
 // which points were settled by k_icp_tile and which by the walk, which varies with the previous pass).
-__global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_sums(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, size_t nt,
+__global__ __launch_bounds__(64 * TILE_WAVES) void k_icp_sums(GridView g, const float4* __restrict__ src, size_t n, Mat34 T, const Mat34* __restrict__ Tdev, size_t nt,
                                                  const float4* __restrict__ pair, int tiles_per_block, double* __restrict__ partials) {
+    if (Tdev) T = *Tdev;              // the transform as the previous pass of a device-side loop left it
     const int lane = (int)(threadIdx.x & 63);
     double acc[ICPX_NSUMS];
 #pragma unroll
@@ -1827,10 +1833,10 @@ static int icp_step_reserve(icpx_ctx* ctx) {
     return ICPX_OK;
 }
 
-static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev, int* idx_dev) {
+static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev, int* idx_dev, const Mat34* Tdev = nullptr) {
     if (!ctx->grid_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_step: no target cloud (call icpx_set_target first)");
     if (ctx->ns == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_step: no source cloud (call icpx_set_source first)");
-    if (!T) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_step: T is NULL");
+    if (!T && !Tdev) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_step: T is NULL");
     // One wave per tile of 64 source points, TILE_WAVES waves per workgroup; 7 workgroups of the tile kernel fit a CU
     // (LDS). The workgroup counts are multiples of 8 (one share of the tiles per XCD).
     const size_t tiles = (ctx->ns + 63) / 64;
@@ -1858,7 +1864,7 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     const unsigned long long counter_base = ctx->tile_counter_base;
     ctx->tile_counter_base += tiles_per_group + (unsigned long long)(blocks / 8) * TILE_WAVES;
     Mat34 M;
-    for (int k = 0; k < 12; k++) M.m[k] = T[k];
+    for (int k = 0; k < 12; k++) M.m[k] = T ? T[k] : 0.0;
     const GridView g = view_of(ctx);
     double* part = ctx->partials.as<double>();
     // A small source cloud (a scan of some ten thousand points) is walked as a whole, eight lanes per point from its previous
@@ -1866,22 +1872,22 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
     // (bunny pair, converged pass: 102 us as tile + walk, 65 us walked)
     const bool walk_all = tiles < ctx->icp_walk_all_tiles;
     if (!walk_all)
-    hipLaunchKernelGGL(k_icp_tile, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
+    hipLaunchKernelGGL(k_icp_tile, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, Tdev, ctx->nt, idx_dev,
                        ctx->nn_pair.as<float4>(), tiles_per_group, ctx->tile_counters.as<unsigned long long>(), counter_base, queue, qcount, tiles_per_shard,
                        far_queue, far_mask);
     if (use_ball)
-        hipLaunchKernelGGL(k_icp_ball, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt, idx_dev,
+        hipLaunchKernelGGL(k_icp_ball, dim3(blocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, Tdev, ctx->nt, idx_dev,
                            ctx->nn_pair.as<float4>(), far_queue, far_mask, queue, qcount, tiles_per_shard, ctx->icp_ball_many, ctx->icp_ball_few);
     if (!walk_all)
-        hipLaunchKernelGGL(k_icp_solo, dim3((unsigned)std::min<size_t>((ctx->ns + 255) / 256, (size_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
+        hipLaunchKernelGGL(k_icp_solo, dim3((unsigned)std::min<size_t>((ctx->ns + 255) / 256, (size_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, Tdev, ctx->nt,
                            queue, qcount, tiles_per_shard, idx_dev, ctx->nn_pair.as<float4>());
     // (what is left to the walk when the tile kernels ran: queries without any candidate, or absurdly far from theirs; the
     // grid is small because launching two thousand workgroups that find nothing to do costs 25 us a pass)
     const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, (size_t)ctx->num_cus * 2 / WALK_SHARDS) * WALK_SHARDS);
     const unsigned all_blocks = (unsigned)std::min<size_t>((ctx->ns + NN_OCTETS - 1) / NN_OCTETS, (size_t)ctx->num_cus * 8);
-    hipLaunchKernelGGL(k_icp_walk, dim3(walk_all ? all_blocks : std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, ctx->nt,
+    hipLaunchKernelGGL(k_icp_walk, dim3(walk_all ? all_blocks : std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, Tdev, ctx->nt,
                        queue, qcount, tiles_per_shard, idx_dev, ctx->nn_pair.as<float4>(), walk_all ? ctx->ns : (size_t)0);
-    hipLaunchKernelGGL(k_icp_sums, dim3(sblocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, ctx->nt,
+    hipLaunchKernelGGL(k_icp_sums, dim3(sblocks), dim3(64 * TILE_WAVES), 0, ctx->stream, g, ctx->src_pts.as<float4>(), ctx->ns, M, Tdev, ctx->nt,
                        ctx->nn_pair.as<float4>(), tiles_per_sblock, part);
     hipLaunchKernelGGL(k_reduce_sums, dim3(ICPX_NSUMS), dim3(256), 0, ctx->stream, part, swaves, sums_dev, qcount, WALK_SHARDS);
 #ifdef ICPX_NN_STATS
@@ -1984,6 +1990,69 @@ extern "C" int icpx_icp_step_trimmed(icpx_ctx* ctx, const double T[16], uint64_t
     ICPX_TRY(icpx_launch_check(ctx, "k_icp_trim_sums"));
     ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sums, ctx->sums.p, ICPX_NSUMS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPX_OK;
+}
+
+// ---- a whole registration loop without the host in between -----------------------------------------------------------
+// SingleThreadIcp::registration (src/SingleThreadIcp.cpp:293-327) runs a fixed number of iterations, each of which
+// needs the previous one's transform and nothing else from the host: the sixteen sums of a pass stay on the device, one
+// thread turns them into the iteration's rigid update with the arithmetic of the host classes (icpx_solve.h: the same
+// statements compiled for both sides) and multiplies it onto the accumulated transform, which the kernels of the next
+// pass read from device memory.
+struct IcpLoopState {
+    double fin[16];          // the accumulated transform (finMat), row-major 4 x 4
+    double mean_tar[3];      // the reference's running target mean (carried from iteration to iteration, :229-231)
+    double pad;
+};
+
+__global__ void k_icp_solve(const double* __restrict__ sums, IcpLoopState* __restrict__ st, double N, double denom, double* __restrict__ trace) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s[ICPX_NSUMS], mean_tar[3], mean_src[3], H[9], T[16], fin[16], fin_old[16], mse_after;
+    for (int k = 0; k < ICPX_NSUMS; k++) s[k] = sums[k];
+    for (int k = 0; k < 3; k++) mean_tar[k] = st->mean_tar[k];
+    for (int k = 0; k < 16; k++) fin_old[k] = st->fin[k];
+    icpx_solve::covariance(s, N, denom, mean_tar, mean_src, H);
+    icpx_solve::best_fit(H, mean_tar, mean_src, s, N, T, &mse_after);
+    icpx_solve::mul4(T, fin_old, fin);
+    for (int k = 0; k < 16; k++) st->fin[k] = fin[k];
+    for (int k = 0; k < 3; k++) st->mean_tar[k] = mean_tar[k];
+    if (trace) {
+        for (int k = 0; k < 16; k++) trace[k] = T[k];
+        trace[16] = mse_after;
+        trace[17] = s[15] / N;
+    }
+}
+
+extern "C" int icpx_icp_run(icpx_ctx* ctx, const double T0[16], int iterations, double mean_tar[3], double T_out[16], double* trace) {
+    if (!ctx) return ICPX_EINVAL;
+    if (!T0 || !mean_tar || !T_out) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_run: NULL argument");
+    if (iterations < 0 || iterations > 1000000) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_icp_run: iterations must be 0 .. 1000000");
+    if (!ctx->grid_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_run: no target cloud (call icpx_set_target first)");
+    if (ctx->ns == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_icp_run: no source cloud (call icpx_set_source first)");
+    ICPX_TRY(icpx_bind(ctx));
+    const size_t state_doubles = sizeof(IcpLoopState) / sizeof(double), trace_doubles = 18 * (size_t)iterations;
+    ICPX_TRY(icpx_reserve(ctx, ctx->icp_loop, (state_doubles + ICPX_NSUMS + trace_doubles) * sizeof(double)));
+    double* base = ctx->icp_loop.as<double>();
+    IcpLoopState* st = reinterpret_cast<IcpLoopState*>(base);
+    double* sums_dev = base + state_doubles;
+    double* trace_dev = sums_dev + ICPX_NSUMS;
+    IcpLoopState h;
+    for (int k = 0; k < 16; k++) h.fin[k] = T0[k];
+    for (int k = 0; k < 3; k++) h.mean_tar[k] = mean_tar[k];
+    h.pad = 0;
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(st, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (h is on this call's stack)
+    const double N = (double)ctx->ns, denom = (double)(float)ctx->ns;   // "/= (float)Nd", src/SingleThreadIcp.cpp:244
+    for (int it = 0; it < iterations; it++) {
+        ICPX_TRY(icp_step_enqueue(ctx, nullptr, sums_dev, nullptr, reinterpret_cast<const Mat34*>(st->fin)));
+        hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(64), 0, ctx->stream, sums_dev, st, N, denom, trace_dev + 18 * (size_t)it);
+    }
+    ICPX_TRY(icpx_launch_check(ctx, "k_icp_solve"));
+    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    if (trace && iterations) ICPX_CHECK_HIP(ctx, hipMemcpyAsync(trace, trace_dev, trace_doubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 16; k++) T_out[k] = h.fin[k];
+    for (int k = 0; k < 3; k++) mean_tar[k] = h.mean_tar[k];
     return ICPX_OK;
 }
 

@@ -42,6 +42,7 @@ def _lib():
                                         C.c_double, C.c_void_p, C.c_void_p]
         lib.icpxh_knn_icp.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.icpxh_icp_device_loop.argtypes = [C.c_void_p, C.c_int]
         lib.icpxh_goicp_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int]
         lib.icpxh_goicp_exact_residuals.argtypes = [C.c_void_p, C.c_int]
         lib.icpxh_goicp_pipeline.argtypes = [C.c_void_p, C.c_int]
@@ -178,10 +179,11 @@ class LDT:
 
 
 class SingleThreadIcp:
-    def __init__(self, source, target, iters=10, device=0, allreduce=None, rank=0, world=1):
+    def __init__(self, source, target, iters=10, device=0, allreduce=None, rank=0, world=1, device_loop=True):
         self._s, self._t = _f32(source), _f32(target)
         self.iters = iters
         self._h = _new(_lib().icpxh_icp_new(device, _vp(self._s), self._s.shape[0], _vp(self._t), self._t.shape[0], iters))
+        _lib().icpxh_icp_device_loop(self._h, int(device_loop))     # False: a host round trip per iteration (same bits)
         self._cb = None
         if world > 1:
             self._cb = make_allreduce(allreduce)

@@ -52,6 +52,7 @@ ICPX_SYMBOLS = {
     "icpx_set_source": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
     "icpx_icp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "icpx_icp_step_trimmed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "icpx_icp_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "icpx_icp_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "icpx_edt_build": (C.c_int, [C.c_void_p, C.c_uint32]),
     "icpx_edt_build_box": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_float]),

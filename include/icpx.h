@@ -111,6 +111,20 @@ int icpx_icp_step(icpx_ctx* ctx, const double T[16], double sums[ICPX_NSUMS], in
  * host reads them. */
 int icpx_icp_step_async(icpx_ctx* ctx, const double T[16], double* sums_dev);
 
+/* The whole loop of SingleThreadIcp::registration (src/SingleThreadIcp.cpp:293-327: for every iteration kdtree_search,
+ * cal_covarance, best_fit_transform, finMat = curMat * finMat) on the context's stream without the host in between:
+ * the sums of a pass stay on the device, one thread forms the means (with the reference's carry-over of the previous
+ * target mean, :229-231), H (/ (float)Nd, :244), the 3x3 SVD with the reflection fix (:256-266) and the update — the
+ * arithmetic of icp::SingleThreadIcp's host code, compiled from the same source, so the result is the host loop's bit
+ * for bit — and the next pass reads the accumulated transform from device memory. For one process holding the whole
+ * source cloud (several ranks exchange their sums between the passes: icpx_icp_step_async).
+ * T0: the starting transform (row-major 4x4, the caller's guess). mean_tar (in / out, 3 doubles): the target mean the
+ * loop starts from (cal_mean of the target, src/SingleThreadIcp.cpp:53, :64) and the running value after the last
+ * iteration. T_out: finMat after `iterations` iterations. trace: NULL, or 18 doubles per iteration: that iteration's
+ * curMat (16, row-major), the residual after its update (sum |T p - q|^2 / Nd over the pairs it was fitted to, :281-288)
+ * and before it (sum |p - q|^2 / Nd). All host memory; the call returns when the loop has finished. */
+int icpx_icp_run(icpx_ctx* ctx, const double T0[16], int iterations, double mean_tar[3], double T_out[16], double* trace);
+
 /* Trimmed form of the same pass, the correspondence step of ICP3D::Run with do_trim
  * (src/jly_icp3d.cpp:210-255): nearest target point of every transformed source point, then the sums of
  * icpx_icp_step over the `keep` pairs with the smallest squared distances only (the reference sorts all

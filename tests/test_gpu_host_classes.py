@@ -68,6 +68,38 @@ def test_icp_bunny_30_iterations(oracle, bunny000, bunny045):
     assert np.abs(again["T"] - ref["T"]).max() < 1e-5
 
 
+def test_icp_loop_on_the_device_equals_the_host_loop(gpu_ctx, oracle, bunny000, bunny045):
+    """SingleThreadIcp::registration as one icpx_icp_run (the iterations follow each other on the GPU; means, covariance,
+    SVD and update by one thread there, compiled from the source of the host code) against the host loop with a round
+    trip per iteration: final transform, every iteration's transform and both residual traces bit for bit, from the
+    identity and from a guess, on a small cloud (every point walked) and on one that goes through the tile kernels."""
+    from icp_amd.host import SingleThreadIcp
+    from conftest import synth_surface
+    rng = np.random.default_rng(3)
+    big_t = synth_surface(120_000, 21)
+    a = 0.05
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    big_s = (big_t[rng.permutation(big_t.shape[0])[:90_000]] @ Rz.T + [0.01, -0.02, 0.005]).astype(np.float32)
+    guess = np.eye(4); guess[:3, :3] = Rz.T; guess[:3, 3] = [0.002, 0.001, -0.003]
+    for src, tgt, iters in ((bunny000, bunny045, 30), (big_s, big_t, 12)):
+        for g in (None, guess):
+            host = SingleThreadIcp(src, tgt, iters=iters, device_loop=False).registration(guess=g)
+            dev = SingleThreadIcp(src, tgt, iters=iters, device_loop=True).registration(guess=g)
+            assert np.array_equal(dev["T"], host["T"])
+            assert np.array_equal(dev["per_iter_T"], host["per_iter_T"])
+            assert np.array_equal(dev["mse"], host["mse"]) and np.array_equal(dev["nn_mse"], host["nn_mse"])
+    # the C ABI by itself: the running target mean comes back, the trace holds curMat and the two residuals
+    gpu_ctx.set_target(bunny045); gpu_ctx.set_source(bunny000)
+    mt0 = bunny045.astype(np.float64).sum(0) / bunny045.shape[0]
+    fin, mt, trace = gpu_ctx.icp_run(np.eye(4), 5, mt0)
+    acc = np.eye(4)
+    for k in range(5):
+        acc = trace[k, :16].reshape(4, 4) @ acc
+    assert np.allclose(acc, fin, rtol=0, atol=1e-12) and trace.shape == (5, 18) and (trace[:, 17] > 0).all() and not np.array_equal(mt, mt0)
+    fin0, mt_same, _ = gpu_ctx.icp_run(guess, 0, mt0)             # no iterations: the guess comes back
+    assert np.array_equal(fin0, guess) and np.array_equal(mt_same, mt0)
+
+
 def test_icp_with_guess(oracle, bunny000, bunny045):
     from icp_amd.host import SingleThreadIcp
     G = rigid([0, 1, 0], 20.0, [0.01, 0.0, -0.01])
