@@ -316,6 +316,12 @@ class Context:
         self._ck(self._lib.icpx_edt_grid_ptr(self._h, C.byref(p)))
         return p.value
 
+    def edt_grid_stride(self):
+        """icpx_edt_grid_stride: values between consecutive rows of the grid behind edt_grid_ptr."""
+        v = C.c_uint32()
+        self._ck(self._lib.icpx_edt_grid_stride(self._h, C.byref(v)))
+        return v.value
+
     def bnb_eval_noalloc(self, items_dev, nitems, out_dev):
         """icpx_bnb_eval_noalloc: items_dev a CUDA uint8 tensor holding `nitems` packed icpx_bnb_item records, out_dev a
         CUDA float64 tensor of 2 * nitems ([ub..., lb...]). Only enqueues on the context's stream: sync() before reading."""

@@ -25,6 +25,7 @@ namespace {
 struct EdtView {
     const int* __restrict__ sq;
     int div;
+    int zs;                                      // values between consecutive rows of sq (z runs fastest)
     float mnx, mny, mnz, cell;
     const unsigned short* __restrict__ bricks;   // the same values in bricks of 4 x 4 x 4 voxels (see k_edt_bricks), or NULL
     int nb;                                      // bricks per axis
@@ -71,7 +72,7 @@ static __device__ __forceinline__ void bnb_eval_item(const EdtView& e, const flo
         const float rx = it.R[0] * p.x + it.R[1] * p.y + it.R[2] * p.z;
         const float ry = it.R[3] * p.x + it.R[4] * p.y + it.R[5] * p.z;
         const float rz = it.R[6] * p.x + it.R[7] * p.y + it.R[8] * p.z;
-        float d = edt_distance(e.sq, e.div, e.mnx, e.mny, e.mnz, e.cell, rx + tx, ry + ty, rz + tz);
+        float d = edt_distance(e.sq, e.div, e.zs, e.mnx, e.mny, e.mnz, e.cell, rx + tx, ry + ty, rz + tz);
         if (mr) d -= mr_i;
         if (d < 0) d = 0;
         if (mindis) mindis[(size_t)item * n + __float_as_int(p.w)] = d;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void k_bnb_eval(EdtView e, const float4* __res
 // the number of lines its lookups touch. Values of 65535 and more are stored as 65535, which sends the reader to the
 // 32-bit grid (voxels more than 255 cells from the surface).
 #define EDT_BRICK_ESCAPE 65535u
-__global__ void k_edt_bricks(const int* __restrict__ sq, int div, int nb, unsigned short* __restrict__ out) {
+__global__ void k_edt_bricks(const int* __restrict__ sq, int div, int zs, int nb, unsigned short* __restrict__ out) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)nb * nb * nb * 64;
     if (e >= total) return;
@@ -112,7 +113,7 @@ __global__ void k_edt_bricks(const int* __restrict__ sq, int div, int nb, unsign
     const unsigned x = bx * 4 + (in >> 4), y = by * 4 + (in >> 2 & 3), z = bz * 4 + (in & 3);
     unsigned v = EDT_BRICK_ESCAPE;
     if (x < (unsigned)div && y < (unsigned)div && z < (unsigned)div) {
-        const unsigned w = (unsigned)sq[((size_t)x * div + y) * div + z];
+        const unsigned w = (unsigned)sq[((size_t)x * div + y) * zs + z];
         v = w < EDT_BRICK_ESCAPE ? w : EDT_BRICK_ESCAPE;
     }
     out[e] = (unsigned short)v;
@@ -121,7 +122,7 @@ __global__ void k_edt_bricks(const int* __restrict__ sq, int div, int nb, unsign
 // The bricks once more with the distance itself in place of the squared cell count: sqrt(v) * cell, rounded as
 // LDT::Distance rounds it (edt_distance_at), so that the bound kernel reads what it would otherwise compute for every
 // lookup (a conversion, a square root made exact, a product: a third of its instructions). 256 bytes per brick.
-__global__ void k_edt_fbricks(const int* __restrict__ sq, int div, int nb, float cell, float* __restrict__ out) {
+__global__ void k_edt_fbricks(const int* __restrict__ sq, int div, int zs, int nb, float cell, float* __restrict__ out) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)nb * nb * nb * 64;
     if (e >= total) return;
@@ -130,7 +131,7 @@ __global__ void k_edt_fbricks(const int* __restrict__ sq, int div, int nb, float
     const unsigned x = bx * 4 + (in >> 4), y = by * 4 + (in >> 2 & 3), z = bz * 4 + (in & 3);
     float v = 0.f;
     if (x < (unsigned)div && y < (unsigned)div && z < (unsigned)div)
-        v = __fmul_rn(edt_sqrt_of_int((float)sq[((size_t)x * div + y) * div + z]), cell);
+        v = __fmul_rn(edt_sqrt_of_int((float)sq[((size_t)x * div + y) * zs + z]), cell);
     out[e] = v;
 }
 
@@ -279,7 +280,7 @@ static __device__ __forceinline__ void bnb_eval8_body(const EdtView& e, const fl
     #pragma unroll
                     for (int j = 0; j < 8; j++)
                         if (v[j] == EDT_BRICK_ESCAPE)
-                            v[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(((cx[j & 1] * (unsigned)e.div + cy[j >> 1 & 1]) * (unsigned)e.div + cz[j >> 2]) * 4u), 0, 0);
+                            v[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(((cx[j & 1] * (unsigned)e.div + cy[j >> 1 & 1]) * (unsigned)e.zs + cz[j >> 2]) * 4u), 0, 0);
                 }
     #pragma unroll
                 for (int j = 0; j < 8; j++) g[j] = (float)v[j];
@@ -289,7 +290,7 @@ static __device__ __forceinline__ void bnb_eval8_body(const EdtView& e, const fl
     #pragma unroll
                 for (int s = 0; s < 2; s++) xoff[s] = cx[s] * (unsigned)e.div;
     #pragma unroll
-                for (int s = 0; s < 4; s++) xyoff[s] = (xoff[s & 1] + cy[s >> 1]) * (unsigned)e.div;
+                for (int s = 0; s < 4; s++) xyoff[s] = (xoff[s & 1] + cy[s >> 1]) * (unsigned)e.zs;
     #pragma unroll
                 for (int j = 0; j < 8; j++)
                     g[j] = (float)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)((xyoff[j & 3] + cz[j >> 2]) * 4u), 0, 0);
@@ -449,12 +450,12 @@ __global__ void k_goicp_residuals(EdtView e, const float4* __restrict__ data, si
         a += T.m[4 * r + 3];
         p[r] = a;
     }
-    out[__float_as_int(s.w)] = edt_distance(e.sq, e.div, e.mnx, e.mny, e.mnz, e.cell, (float)p[0], (float)p[1], (float)p[2]);
+    out[__float_as_int(s.w)] = edt_distance(e.sq, e.div, e.zs, e.mnx, e.mny, e.mnz, e.cell, (float)p[0], (float)p[1], (float)p[2]);
 }
 
 EdtView edt_view(const icpx_ctx* ctx) {
     EdtView e;
-    e.sq = ctx->edt_sq.as<int>(); e.div = (int)ctx->div;
+    e.sq = ctx->edt_sq.as<int>(); e.div = (int)ctx->div; e.zs = (int)ctx->edt_zs;
     e.mnx = ctx->edt_min[0]; e.mny = ctx->edt_min[1]; e.mnz = ctx->edt_min[2]; e.cell = ctx->edt_cell;
     e.bricks = ctx->edt_bricks_ready ? ctx->edt_bricks.as<unsigned short>() : nullptr;
     e.fbricks = ctx->edt_bricks_ready && ctx->edt_fbricks_ready ? ctx->edt_fbricks.as<float>() : nullptr;
@@ -559,14 +560,14 @@ static int bnb_bricks_ensure(icpx_ctx* ctx) {
     if (ctx->edt_bricks_ready) return ICPX_OK;
     const size_t nb = ((size_t)ctx->div + 3) / 4, total = nb * nb * nb * 64;
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_bricks, total * sizeof(unsigned short)));
-    hipLaunchKernelGGL(k_edt_bricks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)ctx->edt_sq.as<int>(), (int)ctx->div, (int)nb,
+    hipLaunchKernelGGL(k_edt_bricks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)ctx->edt_sq.as<int>(), (int)ctx->div, (int)ctx->edt_zs, (int)nb,
                        ctx->edt_bricks.as<unsigned short>());
     ICPX_TRY(icpx_launch_check(ctx, "k_edt_bricks"));
     // the float bricks take 256 bytes per 64 voxels: up to a gigabyte of them (grids of some 640 cells a side)
     ctx->edt_fbricks_ready = false;
     if (ctx->bnb_bricks == 2 && total * sizeof(float) <= ((size_t)1 << 30)) {
         ICPX_TRY(icpx_reserve(ctx, ctx->edt_fbricks, total * sizeof(float)));
-        hipLaunchKernelGGL(k_edt_fbricks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)ctx->edt_sq.as<int>(), (int)ctx->div, (int)nb,
+        hipLaunchKernelGGL(k_edt_fbricks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)ctx->edt_sq.as<int>(), (int)ctx->div, (int)ctx->edt_zs, (int)nb,
                            ctx->edt_cell, ctx->edt_fbricks.as<float>());
         ICPX_TRY(icpx_launch_check(ctx, "k_edt_fbricks"));
         ctx->edt_fbricks_ready = true;

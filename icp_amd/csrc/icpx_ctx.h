@@ -88,6 +88,7 @@ struct icpx_ctx {
     bool edt_ready = false;
     uint32_t div = 0;
     int edt_words = 0;       // 64-bit words per (x,y) bit row
+    uint32_t edt_zs = 0;     // values between consecutive rows of edt_plane / edt_sq (z runs fastest): div, or div rounded up to 32 for large grids (see edt_prepare)
     float edt_min[3] = {0, 0, 0};
     float edt_cell = 0.f;
     bool edt_round = false;  // grid built with DT3D's convention: voxel = int((p - dmin) * scale + 0.5) in double

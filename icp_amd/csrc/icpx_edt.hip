@@ -619,7 +619,7 @@ __device__ __forceinline__ Env<G, POOL> env_setup(unsigned* lds, int parts, int 
 template <int G, bool POOL, int RB>
 __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_zy(const RowRec* __restrict__ recs, const int* __restrict__ rowcnt,
                                                         int* __restrict__ plane, uint2* __restrict__ spill_buf, u64* __restrict__ counters,
-                                                        int div, int W, int cap, int nch, u64* __restrict__ next_counters, int padded,
+                                                        int div, int zs, int W, int cap, int nch, u64* __restrict__ next_counters, int padded,
                                                         int* __restrict__ planelist, int report) {
     extern __shared__ unsigned lds[];
     if (blockIdx.x == (unsigned)(div * W)) {   // the extra workgroup: the plane list for pass x
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_zy(const RowRec* __res
         env_finish(E, g, e, e.deepest + 1, report ? &counters[3] : nullptr);
     }
     __syncthreads();
-    env_write(E, g, G * RB, plane + (size_t)x * div * div + c * 64, (size_t)div, (unsigned)zl & 63u, div);
+    env_write(E, g, G * RB, plane + (size_t)x * div * zs + c * 64, (size_t)zs, (unsigned)zl & 63u, div);
 }
 
 // ---- pass x ---------------------------------------------------------------------------------------------
@@ -689,7 +689,7 @@ constexpr int EDT_ZY_RB = 2, EDT_X_RB = 2;
 template <int G, bool POOL, int RB>
 __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restrict__ plane, const int* __restrict__ planelist,
                                                        u64* __restrict__ counters, int* __restrict__ sq, uint2* __restrict__ spill_buf,
-                                                       int div, int nchunk, int cap, int nch, int report) {
+                                                       int div, int zs, int nchunk, int cap, int nch, int report) {
     constexpr int PF = EDT_PF<POOL>;
     extern __shared__ unsigned lds[];
     // Workgroup ids go round the 8 XCDs: with a chunk count that is a multiple of 8 a plain numbering gives every
@@ -705,11 +705,11 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restric
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int z = min(c * 64 + lane, div - 1);   // lanes beyond the row's end shadow its last voxel: same work, same stores
     const int np = (int)counters[2];
-    const size_t xs = (size_t)div * div;                  // elements between consecutive x
-    const int rowoff = y * div + z;
-    const size_t rowbase = (size_t)y * div + c * 64;   // uniform part of rowoff
+    const size_t xs = (size_t)div * zs;                   // elements between consecutive x (rows are zs values apart)
+    const int rowoff = y * div + z;                       // the row's number (spill buffer)
+    const size_t rowbase = (size_t)y * zs + c * 64;       // uniform part of the row's place in a plane
     const unsigned zl = (unsigned)(z - c * 64) & 63u;   // the lane's part
-    const Env<G, POOL> E = env_setup<G, POOL>(lds, G * RB, cap, nch, lane, spill_buf, div, xs, (size_t)rowoff, &counters[5]);
+    const Env<G, POOL> E = env_setup<G, POOL>(lds, G * RB, cap, nch, lane, spill_buf, div, (size_t)div * div, (size_t)rowoff, &counters[5]);
 
     if (g < G) {
         const int klo = np * g / G, khi = np * (g + 1) / G;
@@ -744,17 +744,17 @@ __global__ __launch_bounds__(64 * G * RB) void k_edt_pass_x(const int* __restric
 }
 
 // ---- lookup (device function in icpx_edt_dev.h) ----
-__global__ void k_edt_lookup(const int* __restrict__ sq, int div, float mnx, float mny, float mnz, float cell,
+__global__ void k_edt_lookup(const int* __restrict__ sq, int div, int zs, float mnx, float mny, float mnz, float cell,
                              const float* __restrict__ q, size_t n, float* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = edt_distance(sq, div, mnx, mny, mnz, cell, q[3 * i], q[3 * i + 1], q[3 * i + 2]);
+    out[i] = edt_distance(sq, div, zs, mnx, mny, mnz, cell, q[3 * i], q[3 * i + 1], q[3 * i + 2]);
 }
 
 // DT3D::Distance (src/jly_3ddt.cpp:821-856) on the exact grid: rounded voxel index; inside the grid the
 // stored distance sqrt(sq) / scale as float; outside, the clamped voxel's distance plus the overshoot in
 // cells (float a, b, c; their squares summed in float; sqrt and division in double) over scale.
-__global__ void k_edt_lookup_round(const int* __restrict__ sq, int div, double mnx, double mny, double mnz, double scale,
+__global__ void k_edt_lookup_round(const int* __restrict__ sq, int div, int zs, double mnx, double mny, double mnz, double scale,
                                    const double* __restrict__ q, size_t n, float* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -765,7 +765,7 @@ __global__ void k_edt_lookup_round(const int* __restrict__ sq, int div, double m
     if (x < 0) { a = (float)x; x = 0; } else if (x >= div) { a = (float)(x - div + 1); x = div - 1; }
     if (y < 0) { b = (float)y; y = 0; } else if (y >= div) { b = (float)(y - div + 1); y = div - 1; }
     if (z < 0) { c = (float)z; z = 0; } else if (z >= div) { c = (float)(z - div + 1); z = div - 1; }
-    const float g = (float)(__dsqrt_rn((double)sq[((size_t)x * div + y) * div + z]) / scale);
+    const float g = (float)(__dsqrt_rn((double)sq[((size_t)x * div + y) * zs + z]) / scale);
     if (a == 0.f && b == 0.f && c == 0.f) { out[i] = g; return; }
     const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fmul_rn(c, c));
     out[i] = (float)(__dsqrt_rn((double)s2) / scale + (double)g);
@@ -856,7 +856,7 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev, int report) {
         auto zy = pool ? (G == 1 ? k_edt_pass_zy<1, true, 1> : G == 2 ? k_edt_pass_zy<2, true, 1> : G == 3 ? k_edt_pass_zy<3, true, 1> : k_edt_pass_zy<4, true, EDT_ZY_RB>)
                        : (G == 1 ? k_edt_pass_zy<1, false, 1> : G == 2 ? k_edt_pass_zy<2, false, 1> : G == 3 ? k_edt_pass_zy<3, false, 1> : k_edt_pass_zy<4, false, EDT_ZY_RB>);
         edt_launch(zy, dim3(div * nchunk + 1), dim3(64 * G * RB), env_lds_bytes(G, G * RB, cap, nch, pool), s, ev, 2, (const RowRec*)ctx->edt_rowlist.as<RowRec>(),
-                   (const int*)ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, counters, div, W, cap, nch,
+                   (const int*)ctx->edt_rowcnt.as<int>(), ctx->edt_plane.as<int>(), spill, counters, div, (int)ctx->edt_zs, W, cap, nch,
                    edt_counter_set(ctx, ctx->edt_epoch ^ 1), (div + 15) / 16 * 16 + 16, ctx->edt_planelist.as<int>(), report);
     }
     {
@@ -865,7 +865,7 @@ static int edt_run_impl(icpx_ctx* ctx, hipEvent_t* ev, int report) {
         auto px = pool ? (G == 1 ? k_edt_pass_x<1, true, 1> : G == 2 ? k_edt_pass_x<2, true, 1> : G == 3 ? k_edt_pass_x<3, true, 1> : k_edt_pass_x<4, true, EDT_X_RB>)
                        : (G == 1 ? k_edt_pass_x<1, false, 1> : G == 2 ? k_edt_pass_x<2, false, 1> : G == 3 ? k_edt_pass_x<3, false, 1> : k_edt_pass_x<4, false, EDT_X_RB>);
         edt_launch(px, dim3(div * nchunk), dim3(64 * G * (G == 4 ? EDT_X_RB : 1)), env_lds_bytes(G, G * (G == 4 ? EDT_X_RB : 1), cap, nch, pool), s, ev, 3, (const int*)ctx->edt_plane.as<int>(),
-                   (const int*)ctx->edt_planelist.as<int>(), counters, ctx->edt_sq.as<int>(), spill, div, nchunk, cap, nch, report);
+                   (const int*)ctx->edt_planelist.as<int>(), counters, ctx->edt_sq.as<int>(), spill, div, (int)ctx->edt_zs, nchunk, cap, nch, report);
     }
     return icpx_launch_check(ctx, "EDT kernels");
 }
@@ -907,7 +907,13 @@ static int edt_prepare(icpx_ctx* ctx, uint32_t div) {
     ctx->edt_ready = false;
     ctx->div = div;
     ctx->edt_words = (int)((div + 63) / 64);
-    const size_t n3 = (size_t)div * div * div;
+    // Rows of the two grids (z runs fastest) start on a 128-byte line when the side is a multiple of 32. Up to some 400
+    // cells a side both grids live in the Infinity Cache and it makes no difference (288 / 300 / 304: pass x 46 / 48 /
+    // 49 us); a grid of gigabytes pays for every row that straddles a line in HBM (bunny045 with rows back to back:
+    // 1008^3 2.2 ms, 1020^3 3.6 ms, 1023^3 3.7 ms; all three 2.04 ms with rows 1024 values apart), so from 512 on the rows
+    // are zs = div rounded up to 32 values apart.
+    ctx->edt_zs = div >= 512 ? (div + 31) / 32 * 32 : div;
+    const size_t n3 = (size_t)div * div * ctx->edt_zs;
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_bits, ((size_t)div * div * ctx->edt_words + 16) * sizeof(u64)));   // + two counter sets
     ICPX_CHECK_HIP(ctx, hipMemsetAsync(ctx->edt_bits.p, 0, ((size_t)div * div * ctx->edt_words + 16) * sizeof(u64), ctx->stream));
     ICPX_TRY(icpx_reserve(ctx, ctx->edt_rowlist, (size_t)div * div * ctx->edt_words * 16));   // RowRec records
@@ -1033,7 +1039,7 @@ extern "C" int icpx_edt_lookup_round(icpx_ctx* ctx, const double* xyz, size_t n,
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         dq = ctx->scratch_q.as<double>(); dout = ctx->scratch_d2.as<float>();
     }
-    hipLaunchKernelGGL(k_edt_lookup_round, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->edt_sq.as<int>(), (int)ctx->div,
+    hipLaunchKernelGGL(k_edt_lookup_round, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->edt_sq.as<int>(), (int)ctx->div, (int)ctx->edt_zs,
                        ctx->edt_dmin[0], ctx->edt_dmin[1], ctx->edt_dmin[2], ctx->edt_scale, dq, n, dout);
     ICPX_TRY(icpx_launch_check(ctx, "k_edt_lookup_round"));
     if (where == ICPX_HOST)
@@ -1094,9 +1100,15 @@ extern "C" int icpx_edt_read(icpx_ctx* ctx, int32_t* sq_out, int where) {
     if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_read: no EDT has been built");
     if (!sq_out) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_edt_read: output is NULL");
     ICPX_TRY(icpx_bind(ctx));
-    const size_t bytes = (size_t)ctx->div * ctx->div * ctx->div * sizeof(int);
-    ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sq_out, ctx->edt_sq.p, bytes, where == ICPX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                                       ctx->stream));
+    // the caller gets div^3 values, rows back to back; the grid's own rows are edt_zs values apart
+    const hipMemcpyKind kind = where == ICPX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (ctx->edt_zs == ctx->div) {
+        const size_t bytes = (size_t)ctx->div * ctx->div * ctx->div * sizeof(int);
+        ICPX_CHECK_HIP(ctx, hipMemcpyAsync(sq_out, ctx->edt_sq.p, bytes, kind, ctx->stream));
+    } else {
+        ICPX_CHECK_HIP(ctx, hipMemcpy2DAsync(sq_out, (size_t)ctx->div * sizeof(int), ctx->edt_sq.p, (size_t)ctx->edt_zs * sizeof(int),
+                                             (size_t)ctx->div * sizeof(int), (size_t)ctx->div * ctx->div, kind, ctx->stream));
+    }
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICPX_OK;
 }
@@ -1105,6 +1117,13 @@ extern "C" int icpx_edt_grid_ptr(icpx_ctx* ctx, const int32_t** sq_dev) {
     if (!ctx || !sq_dev) return ICPX_EINVAL;
     if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_grid_ptr: no EDT has been built");
     *sq_dev = ctx->edt_sq.as<int32_t>();
+    return ICPX_OK;
+}
+
+extern "C" int icpx_edt_grid_stride(icpx_ctx* ctx, uint32_t* stride) {
+    if (!ctx || !stride) return ICPX_EINVAL;
+    if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_edt_grid_stride: no EDT has been built");
+    *stride = ctx->edt_zs;
     return ICPX_OK;
 }
 
@@ -1122,7 +1141,7 @@ extern "C" int icpx_edt_lookup(icpx_ctx* ctx, const float* xyz, size_t n, int wh
         ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->scratch_q.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         dq = ctx->scratch_q.as<float>(); dout = ctx->scratch_d2.as<float>();
     }
-    hipLaunchKernelGGL(k_edt_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->edt_sq.as<int>(), (int)ctx->div,
+    hipLaunchKernelGGL(k_edt_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->edt_sq.as<int>(), (int)ctx->div, (int)ctx->edt_zs,
                        ctx->edt_min[0], ctx->edt_min[1], ctx->edt_min[2], ctx->edt_cell, dq, n, dout);
     ICPX_TRY(icpx_launch_check(ctx, "k_edt_lookup"));
     if (where == ICPX_HOST)

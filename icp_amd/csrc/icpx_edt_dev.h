@@ -79,7 +79,7 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t edt_grid_rsrc(const int
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(sq), 0, -1, 0x00020000);
 }
 
-static __device__ __forceinline__ float edt_distance(const int* __restrict__ sq, int div, float mnx, float mny, float mnz, float cell,
+static __device__ __forceinline__ float edt_distance(const int* __restrict__ sq, int div, int zs, float mnx, float mny, float mnz, float cell,
                                               float x, float y, float z) {
     const float fdiv = (float)div;
     const float mxx = __fadd_rn(mnx, __fmul_rn(cell, fdiv));
@@ -102,7 +102,7 @@ static __device__ __forceinline__ float edt_distance(const int* __restrict__ sq,
         if (cz) qz = __fdiv_rn(az, cell);
     }
     const int ix = min(max((int)qx, 0), div - 1), iy = min(max((int)qy, 0), div - 1), iz = min(max((int)qz, 0), div - 1);
-    const unsigned voxel = ((unsigned)ix * (unsigned)div + (unsigned)iy) * (unsigned)div + (unsigned)iz;
+    const unsigned voxel = ((unsigned)ix * (unsigned)div + (unsigned)iy) * (unsigned)zs + (unsigned)iz;       // rows of the grid are zs values apart
     const __amdgpu_buffer_rsrc_t grid = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(sq), 0, -1, 0x00020000);
     const float g = edt_sqrt_of_int((float)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(voxel * 4u), 0, 0));
     const float inside = __fmul_rn(g, cell);

@@ -64,6 +64,7 @@ ICPX_SYMBOLS = {
     "icpx_edt_last_build": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "icpx_edt_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "icpx_edt_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "icpx_edt_grid_stride": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "icpx_edt_grid_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "icpx_edt_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "icpx_goicp_set_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),

@@ -183,8 +183,13 @@ int icpx_edt_info(icpx_ctx* ctx, uint32_t* div, float min3[3], float* cell_len, 
 /* Copies the squared grid out: div^3 int32 in the reference's [x][y][z] order (z fastest). */
 int icpx_edt_read(icpx_ctx* ctx, int32_t* sq_out, int where);
 
-/* Device address of the squared grid (div^3 int32, [x][y][z]); valid until the next build/destroy. */
+/* Device address of the squared grid as the library holds it, valid until the next build/destroy: int32, voxel
+ * (x, y, z) at ((x * div + y) * stride + z), stride from icpx_edt_grid_stride. The stride is div for grids below 512
+ * cells a side; from 512 on it is div rounded up to a multiple of 32, so that every row starts on a 128-byte line
+ * (icpx_edt_read hands out the plain div^3 array either way). No counterpart in the reference (its LDT keeps the grid
+ * in host memory, src/testLDT.cpp:31-35). */
 int icpx_edt_grid_ptr(icpx_ctx* ctx, const int32_t** sq_dev);
+int icpx_edt_grid_stride(icpx_ctx* ctx, uint32_t* stride);
 
 /* Replaces LDT::Distance (src/testLDT.cpp:235-290): clamp into the box, truncate to a voxel,
  * sqrt(sq) * cellLen + overshoot. A coordinate equal to the upper clamp indexes voxel `div` in the

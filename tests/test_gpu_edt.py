@@ -102,9 +102,54 @@ def test_edt_private_levels_at_two_workgroups_per_cu(oracle, bunny045):
     ctx.close()
 
 
-def test_edt_large_div(gpu_ctx, oracle, bunny045):
-    """div > 511: ten-bit site indices and values above 2^19 in the packed stack entries."""
-    _build_and_check(gpu_ctx, oracle, np.ascontiguousarray(bunny045[::3]), 520)
+def test_edt_large_div(gpu_ctx, oracle, bunny045, bunny000, bun270):
+    """div > 511: ten-bit site indices and values above 2^19 in the packed stack entries. From 512 on the library keeps
+    the grid with rows padded to a multiple of 32 values (520 -> 544): the array handed out, the lookups, the DT3D-style
+    lookups' grid and the bound kernels (plain grid and both brick copies) must not notice."""
+    import ctypes as C
+    import torch
+    pts = np.ascontiguousarray(bunny045[::3])
+    sq, mn, cell = _build_and_check(gpu_ctx, oracle, pts, 520)
+    assert gpu_ctx.edt_grid_stride() == 544
+    rng = np.random.default_rng(8)
+    q = np.ascontiguousarray(np.concatenate([bunny000[::5], rng.uniform(-0.3, 0.3, (4000, 3)).astype(np.float32)]))
+    assert np.array_equal(gpu_ctx.edt_lookup(q), oracle.ldt_lookup(sq, mn, cell, q))
+    # the grid in place: voxel (x, y, z) at (x div + y) stride + z
+    view = torch.empty(520 * 520 * 544, dtype=torch.int32, device="cuda")
+    assert C.CDLL("libamdhip64.so").hipMemcpy(C.c_void_p(view.data_ptr()), C.c_void_p(gpu_ctx.edt_grid_ptr()), C.c_size_t(4 * view.numel()), 3) == 0
+    assert np.array_equal(view.view(520, 520, 544)[:, :, :520].cpu().numpy(), sq)
+    # a multiple of 32 keeps its own side as the stride; below 512 nothing is padded
+    gpu_ctx.edt_build(300); assert gpu_ctx.edt_grid_stride() == 300
+    gpu_ctx.edt_build(512); assert gpu_ctx.edt_grid_stride() == 512
+    # bounds over the padded grid: eight-item kernel on the float bricks, the 16-bit bricks and the plain grid, one-item kernel
+    from icp_amd.api import Context
+    from icp_amd.host import normalize_goicp
+    import os
+    model, data, _ = normalize_goicp(bunny000, bun270)
+    data = np.ascontiguousarray(data[::16])
+    R = oracle.goicp_rotmat(np.array([0.3, -0.2, 0.9], np.float32)).reshape(9)
+    w = np.float32(0.25)
+    cubes = np.array([[np.float32(-0.2) + np.float32(j & 1) * w, np.float32(-0.1) + np.float32(j >> 1 & 1) * w, np.float32(-0.3) + np.float32(j >> 2 & 1) * w, w]
+                      for j in range(8)], np.float32)
+    got = {}
+    for name, group_min, bricks in (("float bricks", "0", "2"), ("16-bit bricks", "0", "1"), ("plain grid", "0", "0"), ("one item", "1000000000", "2")):
+        os.environ["ICPX_BNB_GROUP_MIN"] = group_min; os.environ["ICPX_BNB_BRICKS"] = bricks
+        try:
+            ctx = Context(0)
+            ctx.set_target(model); ctx.edt_build(520); ctx.goicp_set_data(data)
+            assert ctx.edt_grid_stride() == 544
+            got[name] = ctx.bnb_eval(ctx.make_items([R] * 8, cubes, [-1] * 4 + [2] * 4), want_mindis=True)
+            if name == "float bricks":
+                sqm = ctx.edt_read(); infom = ctx.edt_info()
+            ctx.close()
+        finally:
+            del os.environ["ICPX_BNB_GROUP_MIN"], os.environ["ICPX_BNB_BRICKS"]
+    for other in ("16-bit bricks", "plain grid", "one item"):
+        for a, b in zip(got["float bricks"], got[other]):
+            assert np.array_equal(a, b), other
+    rotated = oracle.goicp_rotate(R.reshape(3, 3), data)
+    _, _, rmd = oracle.goicp_bounds(rotated, cubes[:4], sqm, infom["min"], infom["cell"], maxrot=None, want_mindis=True)
+    assert np.array_equal(got["float bricks"][2][:4], rmd)
 
 
 @pytest.mark.parametrize("tune", ["4,2,0", "2,7,4", "1,3,2", "3,5,30", "4,14,1"])

@@ -6,7 +6,7 @@ from icp_amd.api import Context
 pts = np.fromfile("tests/golden/bunny045.xyz.f32", np.float32).reshape(-1, 3)
 ctx = Context(0)
 ctx.set_target(pts)
-for div in (64, 128, 300, 512, 768, 1023):
+for div in [int(a) for a in sys.argv[1:]] or (64, 128, 300, 512, 768, 1023):
     ctx.edt_build(div)
     ctx.edt_build(div)            # second build runs with the LDS shape adapted to the first
     K = 50 if div <= 512 else 10
