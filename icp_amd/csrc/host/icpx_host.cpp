@@ -793,6 +793,13 @@ void GoIcp::collect_parents(int slot, std::vector<float>& ub, std::vector<float>
 // The searches as one call of icpx_bnb_search_run. Searches the device could not finish (a queue beyond its capacity, too
 // many steps) are reset to their start and handed back in `left`.
 bool GoIcp::run_searches_device(const std::vector<Search*>& ss, std::vector<Search*>& left) {
+    if (ss.size() > ICPX_SEARCH_MAX) {               // more than one call takes: in pieces
+        for (size_t lo = 0; lo < ss.size(); lo += ICPX_SEARCH_MAX) {
+            const std::vector<Search*> piece(ss.begin() + lo, ss.begin() + std::min(ss.size(), lo + (size_t)ICPX_SEARCH_MAX));
+            if (!run_searches_device(piece, left)) return false;
+        }
+        return true;
+    }
     std::vector<icpx_bnb_search> in(ss.size());
     std::vector<icpx_bnb_found> out(ss.size());
     for (size_t i = 0; i < ss.size(); i++) {

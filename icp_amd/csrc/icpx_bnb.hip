@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void k_search_eval_step(EdtView e, const float
     }
 }
 
-__global__ void k_search_finish(const SearchState* __restrict__ st, int n, const int* __restrict__ left, icpx_bnb_found* __restrict__ out) {
+__global__ void k_search_finish(const SearchState* __restrict__ st, int n, icpx_bnb_found* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const SearchState s = st[i];
@@ -977,7 +977,6 @@ __global__ void k_search_finish(const SearchState* __restrict__ st, int n, const
     for (int k = 0; k < 4; k++) f.best[k] = s.best[k];
     f.cubes = s.pops;
     f.status = s.status ? s.status : (s.done ? 0 : 2);      // 2: still running when the steps ran out
-    (void)left;
     out[i] = f;
 }
 
@@ -986,7 +985,7 @@ extern "C" int icpx_bnb_search_run(icpx_ctx* ctx, const icpx_bnb_search* searche
     if (steps_out) *steps_out = 0;
     if (n == 0) return ICPX_OK;
     if (!searches || !found) ICPX_FAIL(ctx, ICPX_EINVAL, "icpx_bnb_search_run: NULL argument");
-    if (n > (size_t)1 << 20) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_bnb_search_run: more than 1048576 searches in one call");
+    if (n > ICPX_SEARCH_MAX) ICPX_FAIL(ctx, ICPX_ELIMIT, "icpx_bnb_search_run: more than %d searches in one call", ICPX_SEARCH_MAX);
     if (!ctx->edt_ready) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_search_run: no EDT has been built");
     if (ctx->nd == 0) ICPX_FAIL(ctx, ICPX_ESTATE, "icpx_bnb_search_run: no data cloud (call icpx_goicp_set_data first)");
     for (size_t i = 0; i < n; i++)
@@ -1042,7 +1041,7 @@ extern "C" int icpx_bnb_search_run(icpx_ctx* ctx, const icpx_bnb_search* searche
         running = (size_t)*pin_cnt;
         lot = std::min(2 * lot, ctx->search_lot_max);
     }
-    hipLaunchKernelGGL(k_search_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, st, (int)n, cnt + step, sb[7].as<icpx_bnb_found>());
+    hipLaunchKernelGGL(k_search_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, st, (int)n, sb[7].as<icpx_bnb_found>());
     ICPX_TRY(icpx_launch_check(ctx, "k_search_finish"));
     ICPX_CHECK_HIP(ctx, hipMemcpyAsync(ctx->bnb_pin, sb[7].p, n * sizeof(icpx_bnb_found), hipMemcpyDeviceToHost, ctx->stream));
     ICPX_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));

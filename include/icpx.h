@@ -263,7 +263,9 @@ int icpx_bnb_fetch(icpx_ctx* ctx, int slot, const double* out_dev);
  * found[i]: the best error (the starting value if no child improved on it), whether a cube gave it and that cube, the
  * cubes taken off the queue (8 bound evaluations each) and status: 0 ended as above; 1 the queue outgrew 1024 cubes;
  * 2 still running after 4096 steps. A search with status != 0 holds no result: run it by other means
- * (icpx_bnb_submit). steps_out (may be NULL): steps enqueued (one launch each). */
+ * (icpx_bnb_submit). steps_out (may be NULL): steps enqueued (one launch each). At most ICPX_SEARCH_MAX searches per
+ * call (each holds 21 KB of device memory for its queue while the call runs). */
+#define ICPX_SEARCH_MAX 65536
 typedef struct icpx_bnb_search {
     float R[9];       /* rotation, row-major */
     int32_t level;    /* as icpx_bnb_item.level */
