@@ -12,7 +12,7 @@
 //   * svd3 / kabsch                 == Matrix::svd of src/matrix.cpp (1e-12)
 //   * exact EDT                     ~= DT3D chamfer DT of src/jly_3ddt.cpp (within its approximation error)
 // The ICP trajectory (SingleThreadIcp) and the BnB logic have no runnable reference here; they are
-// pinned only by figures the survey recorded from the reference (tests/test_oracle_cpu.py) —
+// pinned only by figures recorded from runs of the reference before this code was written (tests/test_oracle_cpu.py) —
 // otherwise "parity unpinned".
 //
 // Every function cites the reference lines it restates. Written from scratch; no reference code is

@@ -1,4 +1,4 @@
-# rocprofv3 evidence of the third round (summaries to be copied into profiles/r03_*): kernel-trace stats of the default
+# rocprofv3 evidence behind profiles/r03_* (the summaries are copied there): kernel-trace stats of the default
 # bench command, HBM and SQ counters of the EDT kernels, the counter passes over the 1 M x 1 M ICP kernels (with
 # GRBM_GUI_ACTIVE for the issue fraction), the per-pass kernel times of that pair and the counters of a full Go-ICP run.
 set -e
