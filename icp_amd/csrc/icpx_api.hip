@@ -89,6 +89,7 @@ extern "C" int icpx_create(int device, icpx_ctx** out) {
     { const char* v = getenv("ICPX_SEARCH_FEW"); int x = 0; if (v && sscanf(v, "%d", &x) == 1 && x >= 0) ctx->search_few = x; }
     { const char* v = getenv("ICPX_SEARCH_STEPS"); int x = 0; if (v && sscanf(v, "%d", &x) == 1 && x >= 1) ctx->search_max_steps = x; }
     { const char* v = getenv("ICPX_SEARCH_LOT"); int x = 0, y = 0; if (v && sscanf(v, "%d,%d", &x, &y) == 2 && x >= 1 && y >= x) { ctx->search_lot = x; ctx->search_lot_max = y; } }
+    { const char* v = getenv("ICPX_WALK_WIDE"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->icp_walk_wide_tiles = (size_t)a; }
     { const char* v = getenv("ICPX_BALL_FEW"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->icp_ball_few = (unsigned)a; }
     { const char* v = getenv("ICPX_BALL_MANY"); long long a = 0; if (v && sscanf(v, "%lld", &a) == 1 && a >= 0) ctx->icp_ball_many = (unsigned)a; }
     // ICPX_BNB_GROUP_MIN: bound batches of at least this many items go through the kernel that takes eight items per

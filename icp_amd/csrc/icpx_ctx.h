@@ -72,6 +72,7 @@ struct icpx_ctx {
     DevBuf nn_seed;          // ns int, by sorted source position: position in sorted_pts of the target point the source point was paired with by the last ICP pass, -1 = none
     DevBuf tile_counters;    // eight 64-bit counters, 64 B apart, that hand out the tiles of an ICP pass; never reset
     unsigned long long tile_counter_base = 0;   // their common value before the next launch
+    size_t icp_walk_wide_tiles = 65536;         // source clouds with at least this many tiles (4 M points) launch the walk kernel over the whole GPU (ICPX_WALK_WIDE)
     size_t icp_walk_all_tiles = 1024;           // source clouds with fewer tiles skip the tile kernel: every point is walked (ICPX_ICP_TILES)
     size_t icp_ball_min_tiles = 2048;           // source clouds with at least this many tiles use the ball kernel for far tiles
     unsigned icp_ball_few = 1024;               // with fewer far tiles than this the ball kernel hands their open lanes to k_icp_solo (ICPX_BALL_FEW)

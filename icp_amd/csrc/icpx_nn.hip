@@ -1882,8 +1882,12 @@ static int icp_step_enqueue(icpx_ctx* ctx, const double T[16], double* sums_dev,
         hipLaunchKernelGGL(k_icp_solo, dim3((unsigned)std::min<size_t>((ctx->ns + 255) / 256, (size_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, Tdev, ctx->nt,
                            queue, qcount, tiles_per_shard, idx_dev, ctx->nn_pair.as<float4>());
     // (what is left to the walk when the tile kernels ran: queries without any candidate, or absurdly far from theirs; the
-    // grid is small because launching two thousand workgroups that find nothing to do costs 25 us a pass)
-    const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, (size_t)ctx->num_cus * 2 / WALK_SHARDS) * WALK_SHARDS);
+    // grid is small because launching two thousand workgroups that find nothing to do costs 25 us a pass. A cloud of
+    // many millions of points has smaller cells, the same offset is more cells, and the first passes leave the walk
+    // hundreds of thousands of queries more than 40 cells from their candidates: there the full grid pays,
+    // 16 M pair, first pass: walk kernel 10.9 ms with 512 workgroups)
+    const size_t walk_cap = (size_t)ctx->num_cus * (tiles >= ctx->icp_walk_wide_tiles ? 8 : 2);
+    const unsigned walk_blocks = (unsigned)(std::min<size_t>((tiles * 2 + WALK_SHARDS - 1) / WALK_SHARDS, walk_cap / WALK_SHARDS) * WALK_SHARDS);
     const unsigned all_blocks = (unsigned)std::min<size_t>((ctx->ns + NN_OCTETS - 1) / NN_OCTETS, (size_t)ctx->num_cus * 8);
     hipLaunchKernelGGL(k_icp_walk, dim3(walk_all ? all_blocks : std::max(walk_blocks, (unsigned)WALK_SHARDS)), dim3(256), 0, ctx->stream, g, ctx->src_pts.as<float4>(), M, Tdev, ctx->nt,
                        queue, qcount, tiles_per_shard, idx_dev, ctx->nn_pair.as<float4>(), walk_all ? ctx->ns : (size_t)0);
