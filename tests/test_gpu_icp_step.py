@@ -139,6 +139,8 @@ def test_icp_step_far_from_the_surface_all_pairs(oracle, monkeypatch, path):
     tgt = np.ascontiguousarray(np.concatenate([base, base[5000:8000]]))
     src = synth_surface(n, 8, noise=1e-3)
     monkeypatch.setenv("ICPX_ICP_TILES", PATHS[path])
+    if path == "tile + ball + walk":
+        monkeypatch.setenv("ICPX_WALK_WIDE", "0")      # and the walk kernel launched over the whole GPU, as for clouds of 4 M points and more
     ctx = Context(0)
     try:
         ctx.set_target(tgt)
